@@ -1,0 +1,338 @@
+// fusion.hip -- PointFusion map update: similarity test (C), unique best correspondence per pixel
+// (U), confidence-weighted merge (F) and the new-point mask (A).
+//
+// All HBM/L2-bound gathers keyed by the [b,n,h,w] table.  U replaces the reference's lexicographic
+// row sort (torch.unique(dim=0) over P x 6 floats, ~90 % of its mapping time) by two per-pixel atomic
+// min passes on order-preserving integer keys followed by a stable compaction over pixels, which
+// yields the identical winners in the identical (b,h,w) output order.
+#include "gs_common.hpp"
+#include "gs_compact.hpp"
+
+namespace gs {
+
+// ------------------------------------------------------------------ C
+__global__ void similar_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n, const float *__restrict__ gv,
+                          const float *__restrict__ gn, int H, int W, const float *__restrict__ mp,
+                          const float *__restrict__ mn, int Nmax, float dist_th, float dot_th, uint8_t *__restrict__ keep,
+                          float *__restrict__ max_dot) {
+    const int n = *d_n;
+    float md = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const int64_t pix = ((int64_t)r.x * H + r.z) * W + r.w;
+        const int64_t pt = (int64_t)r.x * Nmax + r.y;
+        const f3 fv = ld3(gv, pix), fn = ld3(gn, pix), p = ld3(mp, pt), q = ld3(mn, pt);
+        const float dx = fv.x - p.x, dy = fv.y - p.y, dz = fv.z - p.z;
+        // (a-b).norm(dim=-1): sqrt(fma(z,z,fma(y,y,x*x)));  (a*b).sum(-1): unfused
+        const float dist = sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+        const float dot = (fn.x * q.x + fn.y * q.y) + fn.z * q.z;
+        keep[i] = (dist < dist_th && dot > dot_th) ? 1 : 0;
+        md = fmaxf(md, dot);
+    }
+    if (max_dot) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) md = fmaxf(md, __shfl_xor(md, off, kWave));
+        if ((threadIdx.x & 63) == 0 && md > 0.0f) atomicMax(reinterpret_cast<int *>(max_dot), __float_as_int(md));
+    }
+}
+
+// ------------------------------------------------------------------ U
+// key = (1/(c + 1e-20), squared ray distance) as order-preserving bits (both are >= +0)
+__device__ __forceinline__ unsigned long long unique_key(const float *__restrict__ gv, const float *__restrict__ mp,
+                                                         const float *__restrict__ cc, int64_t pix, int64_t pt) {
+    const float inv_c = 1.0f / (cc[pt] + 1e-20f);
+    const f3 fv = ld3(gv, pix), p = ld3(mp, pt);
+    const float dx = p.x - fv.x, dy = p.y - fv.y, dz = p.z - fv.z;
+    const float ray = (dx * dx + dy * dy) + dz * dz;  // ((a-b)**2).sum(-1): unfused
+    return ((unsigned long long)fbits(inv_c) << 32) | fbits(ray);
+}
+
+__global__ void unique_pass1_k(const int64_t *__restrict__ rows, const uint8_t *__restrict__ keep,
+                               const int32_t *__restrict__ d_n, const float *__restrict__ gv, int H, int W,
+                               const float *__restrict__ mp, const float *__restrict__ cc, int Nmax,
+                               unsigned long long *__restrict__ pix_key) {
+    const int n = *d_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (keep && !keep[i]) continue;
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const int64_t pix = ((int64_t)r.x * H + r.z) * W + r.w;
+        atomicMin(pix_key + pix, unique_key(gv, mp, cc, pix, (int64_t)r.x * Nmax + r.y));
+    }
+}
+__global__ void unique_pass2_k(const int64_t *__restrict__ rows, const uint8_t *__restrict__ keep,
+                               const int32_t *__restrict__ d_n, const float *__restrict__ gv, int H, int W,
+                               const float *__restrict__ mp, const float *__restrict__ cc, int Nmax,
+                               const unsigned long long *__restrict__ pix_key, unsigned int *__restrict__ pix_n) {
+    const int n = *d_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (keep && !keep[i]) continue;
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const int64_t pix = ((int64_t)r.x * H + r.z) * W + r.w;
+        if (unique_key(gv, mp, cc, pix, (int64_t)r.x * Nmax + r.y) == pix_key[pix]) atomicMin(pix_n + pix, (unsigned int)r.y);
+    }
+}
+struct PixPred {
+    const unsigned int *pix_n;
+    __device__ bool operator()(int64_t i) const { return pix_n[i] != 0xffffffffu; }
+};
+struct PixWriter {
+    const unsigned int *pix_n;
+    int64_t *rows;
+    int H, W;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int64_t hw = (int64_t)H * W;
+        const int b = (int)(i / hw);
+        const int rem = (int)(i - (int64_t)b * hw);
+        longlong4 r;
+        r.x = b; r.y = pix_n[i]; r.z = rem / W; r.w = rem % W;
+        *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
+    }
+};
+
+// ------------------------------------------------------------------ F
+__global__ void fill_i32_k(int *__restrict__ p, int64_t n, int v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void scatter_match_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n, int H, int W, int Nmax,
+                                int *__restrict__ match_pix) {
+    const int n = *d_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        match_pix[(int64_t)r.x * Nmax + r.y] = (int)(r.z * W + r.w);
+    }
+}
+// Every map point goes through the reference's formula, matched or not: an unmatched point becomes
+// (c*x + 0*0) * (1/c), which is NOT bit-identical to x -- part of the reference's observable result
+// (slam/fusionutils.py:678-699 operate on the whole padded tensors).
+__global__ void merge_k(const int *__restrict__ match_pix, const int32_t *__restrict__ counts, int Nmax, int HW,
+                        const float *__restrict__ gv, const float *__restrict__ gn, const float *__restrict__ rgb,
+                        const float *__restrict__ alpha, const float *__restrict__ ip, const float *__restrict__ inn,
+                        const float *__restrict__ ic, const float *__restrict__ icc, float *__restrict__ op,
+                        float *__restrict__ on, float *__restrict__ oc, float *__restrict__ occ) {
+    const int b = blockIdx.y;
+    const int cnt = counts[b];
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Nmax; n += gridDim.x * blockDim.x) {
+        const int64_t pt = (int64_t)b * Nmax + n;
+        if (n >= cnt) {  // padding stays zero
+            st3(op, pt, f3{0, 0, 0}); st3(on, pt, f3{0, 0, 0}); st3(oc, pt, f3{0, 0, 0}); occ[pt] = 0.0f;
+            continue;
+        }
+        const int m = match_pix[pt];
+        float a = 0.0f;
+        f3 fp{0, 0, 0}, fn{0, 0, 0}, fc{0, 0, 0};
+        if (m >= 0) {
+            const int64_t pix = (int64_t)b * HW + m;
+            a = alpha[pix]; fp = ld3(gv, pix); fn = ld3(gn, pix); fc = ld3(rgb, pix);
+        }
+        const float c = icc[pt];
+        const float c2 = c + a;
+        const float inv = 1.0f / (c2 == 0.0f ? 1.0f : c2);
+        const f3 x = ld3(ip, pt), y = ld3(inn, pt), z = ld3(ic, pt);
+        st3(op, pt, f3{((c * x.x) + (a * fp.x)) * inv, ((c * x.y) + (a * fp.y)) * inv, ((c * x.z) + (a * fp.z)) * inv});
+        st3(on, pt, f3{((c * y.x) + (a * fn.x)) * inv, ((c * y.y) + (a * fn.y)) * inv, ((c * y.z) + (a * fn.z)) * inv});
+        st3(oc, pt, f3{((c * z.x) + (a * fc.x)) * inv, ((c * z.y) + (a * fc.y)) * inv, ((c * z.z) + (a * fc.z)) * inv});
+        occ[pt] = c2;
+    }
+}
+
+// adjoint of merge_k.  x' = (c x + a xf) / c2 (c2 != 0):
+//   x_bar = (c/c2) x'_bar ; xf_bar = (a/c2) x'_bar ; c_bar = c2_bar + sum (x - x').x'_bar / c2 ;
+//   a_bar = c2_bar + sum (xf - x').x'_bar / c2      (sums over points, normals, colours)
+__global__ void merge_bwd_k(const int *__restrict__ match_pix, const int32_t *__restrict__ counts, int Nmax, int HW,
+                            const float *__restrict__ gv, const float *__restrict__ gn, const float *__restrict__ rgb,
+                            const float *__restrict__ alpha, const float *__restrict__ ip, const float *__restrict__ inn,
+                            const float *__restrict__ ic, const float *__restrict__ icc, const float *__restrict__ gop,
+                            const float *__restrict__ gon, const float *__restrict__ goc, const float *__restrict__ gocc,
+                            float *__restrict__ gip, float *__restrict__ ginn, float *__restrict__ gic,
+                            float *__restrict__ gicc, float *__restrict__ ggv, float *__restrict__ ggn,
+                            float *__restrict__ grgb, float *__restrict__ galpha) {
+    const int b = blockIdx.y;
+    const int cnt = counts[b];
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Nmax; n += gridDim.x * blockDim.x) {
+        const int64_t pt = (int64_t)b * Nmax + n;
+        if (n >= cnt) {
+            if (gip) st3(gip, pt, f3{0, 0, 0});
+            if (ginn) st3(ginn, pt, f3{0, 0, 0});
+            if (gic) st3(gic, pt, f3{0, 0, 0});
+            if (gicc) gicc[pt] = 0.0f;
+            continue;
+        }
+        const int m = match_pix[pt];
+        const int64_t pix = (int64_t)b * HW + (m >= 0 ? m : 0);
+        float a = 0.0f;
+        f3 fp{0, 0, 0}, fn{0, 0, 0}, fc{0, 0, 0};
+        if (m >= 0) { a = alpha[pix]; fp = ld3(gv, pix); fn = ld3(gn, pix); fc = ld3(rgb, pix); }
+        const float c = icc[pt], c2 = c + a;
+        const float inv = 1.0f / (c2 == 0.0f ? 1.0f : c2);
+        const f3 x = ld3(ip, pt), y = ld3(inn, pt), z = ld3(ic, pt);
+        const f3 gx = gop ? ld3(gop, pt) : f3{0, 0, 0}, gy = gon ? ld3(gon, pt) : f3{0, 0, 0},
+                 gz = goc ? ld3(goc, pt) : f3{0, 0, 0};
+        const float gc2 = gocc ? gocc[pt] : 0.0f;
+        if (gip) st3(gip, pt, f3{c * inv * gx.x, c * inv * gx.y, c * inv * gx.z});
+        if (ginn) st3(ginn, pt, f3{c * inv * gy.x, c * inv * gy.y, c * inv * gy.z});
+        if (gic) st3(gic, pt, f3{c * inv * gz.x, c * inv * gz.y, c * inv * gz.z});
+        // d x'/d c2 = -(c x + a xf) inv^2 = -x' inv (zero when c2 == 0, where the where() picks the constant 1)
+        const f3 xo{((c * x.x) + (a * fp.x)) * inv, ((c * x.y) + (a * fp.y)) * inv, ((c * x.z) + (a * fp.z)) * inv};
+        const f3 yo{((c * y.x) + (a * fn.x)) * inv, ((c * y.y) + (a * fn.y)) * inv, ((c * y.z) + (a * fn.z)) * inv};
+        const f3 zo{((c * z.x) + (a * fc.x)) * inv, ((c * z.y) + (a * fc.y)) * inv, ((c * z.z) + (a * fc.z)) * inv};
+        const float dinv = (c2 == 0.0f) ? 0.0f : 1.0f;
+        const float s_out = (xo.x * gx.x + xo.y * gx.y + xo.z * gx.z) + (yo.x * gy.x + yo.y * gy.y + yo.z * gy.z) +
+                            (zo.x * gz.x + zo.y * gz.y + zo.z * gz.z);
+        const float s_in = (x.x * gx.x + x.y * gx.y + x.z * gx.z) + (y.x * gy.x + y.y * gy.y + y.z * gy.z) +
+                           (z.x * gz.x + z.y * gz.y + z.z * gz.z);
+        const float s_f = (fp.x * gx.x + fp.y * gx.y + fp.z * gx.z) + (fn.x * gy.x + fn.y * gy.y + fn.z * gy.z) +
+                          (fc.x * gz.x + fc.y * gz.y + fc.z * gz.z);
+        if (gicc) gicc[pt] = gc2 + (s_in - dinv * s_out) * inv;
+        if (m >= 0) {  // unique rows: one map point per pixel -> plain stores
+            if (ggv) st3(ggv, pix, f3{a * inv * gx.x, a * inv * gx.y, a * inv * gx.z});
+            if (ggn) st3(ggn, pix, f3{a * inv * gy.x, a * inv * gy.y, a * inv * gy.z});
+            if (grgb) st3(grgb, pix, f3{a * inv * gz.x, a * inv * gz.y, a * inv * gz.z});
+            if (galpha) galpha[pix] = gc2 + (s_f - dinv * s_out) * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ A
+__global__ void valid_mask_k(const float *__restrict__ depth, int64_t n, uint8_t *__restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = depth[i] > 0.0f ? 1 : 0;
+}
+__global__ void clear_matched_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n, int H, int W,
+                                uint8_t *__restrict__ mask) {
+    const int n = *d_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        mask[((int64_t)r.x * H + r.z) * W + r.w] = 0;
+    }
+}
+
+static inline int grid1d(int64_t n) { int g = cdiv(n > 0 ? n : 1, 256); return g > 2048 ? 2048 : g; }
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gs_fusion_similar(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
+                      const float *gnormal, int H, int W, const float *map_points, const float *map_normals, int Nmax,
+                      float dist_th, float dot_th, uint8_t *keep, float *max_dot, gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && gvertex && gnormal && map_points && map_normals && keep, "gs_fusion_similar: NULL argument");
+    GS_REQUIRE(H > 0 && W > 0 && Nmax > 0 && max_rows >= 0, "gs_fusion_similar: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (max_dot) GS_HIP(hipMemsetAsync(max_dot, 0, sizeof(float), st), "gs_fusion_similar/memset");
+    if (max_rows == 0) return GS_OK;
+    hipLaunchKernelGGL(similar_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, d_n_rows, gvertex, gnormal, H, W,
+                       map_points, map_normals, Nmax, dist_th, dot_th, keep, max_dot);
+    GS_LAUNCH_CHECK("gs_fusion_similar");
+    return GS_OK;
+}
+
+size_t gs_fusion_unique_ws_bytes(int B, int H, int W) {
+    const size_t npix = (size_t)B * H * W;
+    return align_up(npix * 8, 256) + align_up(npix * 4, 256) + compact_ws_bytes((int64_t)npix);
+}
+
+int gs_fusion_unique(const int64_t *rows, const uint8_t *keep, const int32_t *d_n_rows, int64_t max_rows,
+                     const float *gvertex, int B, int H, int W, const float *map_points, const float *map_ccounts,
+                     int Nmax, int64_t *out_rows, int32_t *out_count, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && gvertex && map_points && map_ccounts && out_rows && out_count, "gs_fusion_unique: NULL argument");
+    GS_REQUIRE(B > 0 && H > 0 && W > 0 && Nmax > 0 && max_rows >= 0, "gs_fusion_unique: bad shape");
+    if (!ws || ws_bytes < gs_fusion_unique_ws_bytes(B, H, W)) {
+        set_error("gs_fusion_unique: workspace too small (%zu < %zu)", ws_bytes, gs_fusion_unique_ws_bytes(B, H, W));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    unsigned long long *pix_key = (unsigned long long *)ws;
+    unsigned int *pix_n = (unsigned int *)((char *)ws + align_up(npix * 8, 256));
+    void *cws = (char *)pix_n + align_up(npix * 4, 256);
+    GS_HIP(hipMemsetAsync(pix_key, 0xff, npix * 8, st), "gs_fusion_unique/memset");
+    GS_HIP(hipMemsetAsync(pix_n, 0xff, npix * 4, st), "gs_fusion_unique/memset");
+    if (max_rows > 0) {
+        hipLaunchKernelGGL(unique_pass1_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, keep, d_n_rows, gvertex, H, W,
+                           map_points, map_ccounts, Nmax, pix_key);
+        GS_LAUNCH_CHECK("gs_fusion_unique/1");
+        hipLaunchKernelGGL(unique_pass2_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, keep, d_n_rows, gvertex, H, W,
+                           map_points, map_ccounts, Nmax, pix_key, pix_n);
+        GS_LAUNCH_CHECK("gs_fusion_unique/2");
+    }
+    PixPred pred{pix_n};
+    PixWriter wr{pix_n, out_rows, H, W};
+    return compact_launch((int64_t)npix, pred, wr, out_count, cws, st, "gs_fusion_unique/compact");
+}
+
+size_t gs_fusion_merge_ws_bytes(int B, int Nmax) { return align_up((size_t)B * Nmax * 4, 256); }
+
+static int build_match(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H, int W, int Nmax,
+                       void *ws, size_t ws_bytes, hipStream_t st, const char *name) {
+    if (!ws || ws_bytes < gs_fusion_merge_ws_bytes(B, Nmax)) {
+        set_error("%s: workspace too small", name);
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipLaunchKernelGGL(fill_i32_k, dim3(grid1d((int64_t)B * Nmax)), dim3(256), 0, st, (int *)ws, (int64_t)B * Nmax, -1);
+    GS_LAUNCH_CHECK(name);
+    if (max_rows > 0) {
+        hipLaunchKernelGGL(scatter_match_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, d_n_rows, H, W, Nmax, (int *)ws);
+        GS_LAUNCH_CHECK(name);
+    }
+    return GS_OK;
+}
+
+int gs_fusion_merge(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
+                    const float *gnormal, const float *rgb, const float *alpha, int B, int H, int W, int Nmax,
+                    const int32_t *counts, const float *in_points, const float *in_normals, const float *in_colors,
+                    const float *in_ccounts, float *out_points, float *out_normals, float *out_colors,
+                    float *out_ccounts, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && gvertex && gnormal && rgb && alpha && counts, "gs_fusion_merge: NULL argument");
+    GS_REQUIRE(in_points && in_normals && in_colors && in_ccounts && out_points && out_normals && out_colors && out_ccounts,
+               "gs_fusion_merge: NULL map array");
+    GS_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && Nmax > 0 && max_rows >= 0, "gs_fusion_merge: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_match(rows, d_n_rows, max_rows, B, H, W, Nmax, ws, ws_bytes, st, "gs_fusion_merge");
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(merge_k, dim3(grid1d(Nmax), B), dim3(256), 0, st, (const int *)ws, counts, Nmax, H * W, gvertex,
+                       gnormal, rgb, alpha, in_points, in_normals, in_colors, in_ccounts, out_points, out_normals,
+                       out_colors, out_ccounts);
+    GS_LAUNCH_CHECK("gs_fusion_merge");
+    return GS_OK;
+}
+
+int gs_fusion_merge_backward(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
+                             const float *gnormal, const float *rgb, const float *alpha, int B, int H, int W, int Nmax,
+                             const int32_t *counts, const float *in_points, const float *in_normals,
+                             const float *in_colors, const float *in_ccounts, const float *g_out_points,
+                             const float *g_out_normals, const float *g_out_colors, const float *g_out_ccounts,
+                             float *g_in_points, float *g_in_normals, float *g_in_colors, float *g_in_ccounts,
+                             float *g_gvertex, float *g_gnormal, float *g_rgb, float *g_alpha, void *ws, size_t ws_bytes,
+                             gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && gvertex && gnormal && rgb && alpha && counts, "gs_fusion_merge_backward: NULL argument");
+    GS_REQUIRE(in_points && in_normals && in_colors && in_ccounts, "gs_fusion_merge_backward: NULL map array");
+    GS_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && Nmax > 0 && max_rows >= 0, "gs_fusion_merge_backward: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_match(rows, d_n_rows, max_rows, B, H, W, Nmax, ws, ws_bytes, st, "gs_fusion_merge_backward");
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(merge_bwd_k, dim3(grid1d(Nmax), B), dim3(256), 0, st, (const int *)ws, counts, Nmax, H * W, gvertex,
+                       gnormal, rgb, alpha, in_points, in_normals, in_colors, in_ccounts, g_out_points, g_out_normals,
+                       g_out_colors, g_out_ccounts, g_in_points, g_in_normals, g_in_colors, g_in_ccounts, g_gvertex,
+                       g_gnormal, g_rgb, g_alpha);
+    GS_LAUNCH_CHECK("gs_fusion_merge_backward");
+    return GS_OK;
+}
+
+int gs_fusion_new_mask(const float *depth, const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H,
+                       int W, uint8_t *mask, gs_stream_t stream) {
+    GS_REQUIRE(depth && mask && B > 0 && H > 0 && W > 0 && max_rows >= 0, "gs_fusion_new_mask: bad arguments");
+    GS_REQUIRE(max_rows == 0 || (rows && d_n_rows), "gs_fusion_new_mask: rows/d_n_rows NULL with max_rows > 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(valid_mask_k, dim3(grid1d(n)), dim3(256), 0, st, depth, n, mask);
+    GS_LAUNCH_CHECK("gs_fusion_new_mask/valid");
+    if (max_rows > 0) {
+        hipLaunchKernelGGL(clear_matched_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, d_n_rows, H, W, mask);
+        GS_LAUNCH_CHECK("gs_fusion_new_mask/clear");
+    }
+    return GS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// gs_compact.hpp -- order-preserving (stable) stream compaction skeleton.
+//
+// The reference selects rows with boolean-mask indexing (x[mask]) whose output order is the input
+// order; map-point order and (h,w) row-major append order are user-visible, so the compaction
+// must be stable.  Three launches: per-block counts -> single-block scan -> ordered write.  The
+// predicate is re-evaluated in the write pass (cheap, inputs are L2/MALL resident) instead of
+// materialising flags.  No inter-workgroup hand-off inside a launch, so no coherence protocol.
+#pragma once
+
+#include "gs_common.hpp"
+
+namespace gs {
+
+constexpr int kCT = 256;               // threads per block
+constexpr int kCI = 4;                 // consecutive items per thread
+constexpr int kCB = kCT * kCI;         // items per block
+
+static inline int compact_blocks(int64_t n) { return n > 0 ? cdiv(n, kCB) : 1; }
+// workspace: block_counts[nb] + block_offsets[nb]
+static inline size_t compact_ws_bytes(int64_t n) { return align_up(2 * sizeof(int) * (size_t)compact_blocks(n), 256); }
+
+template <class Pred>
+__global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts) {
+    __shared__ int sm[kCT / 64];
+    const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kCI; ++k) {
+        const int64_t i = base + k;
+        if (i < n && pred(i)) ++c;
+    }
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < kCT / 64; ++w) s += sm[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+// single block; out_total[0] = sum, optionally added to *accum_base first (for segmented use)
+static __global__ __launch_bounds__(1024) void compact_scan_k(const int *__restrict__ block_counts, int nblocks,
+                                                       int *__restrict__ block_offsets, int *__restrict__ out_total) {
+    __shared__ int sm[1024 / 64 + 1];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int start = 0; start < nblocks; start += 1024) {
+        const int i = start + threadIdx.x;
+        const int v = i < nblocks ? block_counts[i] : 0;
+        int total;
+        const int ex = block_excl_scan<1024>(v, sm, &total);
+        if (i < nblocks) block_offsets[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && out_total) out_total[0] = carry;
+}
+
+template <class Pred, class Writer>
+__global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Writer writer,
+                                                       const int *__restrict__ block_offsets) {
+    __shared__ int sm[kCT / 64 + 1];
+    const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
+    bool f[kCI];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kCI; ++k) {
+        const int64_t i = base + k;
+        f[k] = (i < n) && pred(i);
+        c += f[k] ? 1 : 0;
+    }
+    int total;
+    int pos = block_offsets[blockIdx.x] + block_excl_scan<kCT>(c, sm, &total);
+#pragma unroll
+    for (int k = 0; k < kCI; ++k) {
+        if (f[k]) {
+            writer(base + k, (int64_t)pos);
+            ++pos;
+        }
+    }
+}
+
+// Enqueue the three launches.  ws must hold compact_ws_bytes(n).
+template <class Pred, class Writer>
+static inline int compact_launch(int64_t n, Pred pred, Writer writer, int *d_out_count, void *ws,
+                                 hipStream_t st, const char *name) {
+    const int nb = compact_blocks(n);
+    int *counts = (int *)ws;
+    int *offsets = counts + nb;
+    hipLaunchKernelGGL((compact_count_k<Pred>), dim3(nb), dim3(kCT), 0, st, n, pred, counts);
+    GS_LAUNCH_CHECK(name);
+    hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, st, counts, nb, offsets, d_out_count);
+    GS_LAUNCH_CHECK(name);
+    hipLaunchKernelGGL((compact_write_k<Pred, Writer>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, offsets);
+    GS_LAUNCH_CHECK(name);
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -1,0 +1,767 @@
+// icp.hip -- exact 1-NN association (K), linearise + 6x6 reduce (J), the O(1) solve / SE(3)
+// exponential / LM control (X), and whole ICP / gradICP loops that never leave the device.
+//
+// K is FP32-VALU bound (8 flop per src x tgt pair, no dense contraction -> no MFMA; an
+// |p|^2+|q|^2-2p.q MFMA form would change rounding and tie-breaks).  The target cloud is read with
+// wave-uniform addresses, so it streams through the scalar cache into SGPRs and costs no VGPRs or LDS
+// bandwidth; the launch is split over (source tiles) x (target ranges) to fill 256 CUs even when
+// there are only ~19 k source points, and partial winners are merged with one 64-bit atomic min
+// per (point, range) on the packed key  dist_bits<<32 | index  (min distance, then lowest index:
+// exactly the reference's strict-< scan order).
+// J is a gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; it
+// reduces with wave butterflies and a fixed-order two-level tree (deterministic, no float atomics).
+#include "gs_common.hpp"
+
+namespace gs {
+
+constexpr int KNN_T = 256;   // threads per block
+constexpr int KNN_SPT = 2;   // source points per thread
+constexpr int KNN_TILE = KNN_T * KNN_SPT;
+constexpr int NACC = 29;     // 21 (upper H) + 6 (g) + e + count
+constexpr int LIN_T = 256;
+constexpr int LIN_MAXB = 1024;  // max partial blocks
+
+// ------------------------------------------------------------------ K
+// src_in -> (optional rigid transform by the DEVICE 4x4 `T`) -> src_out (written by range 0 only)
+// -> nearest target in this block's target range -> atomic min into best[].
+__global__ __launch_bounds__(KNN_T) void knn1_k(const float *__restrict__ src_in, const int32_t *__restrict__ d_ns,
+                                                const float *__restrict__ T, float *__restrict__ src_out,
+                                                const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
+                                                int nsplit, unsigned long long *__restrict__ best) {
+    const int ns = *d_ns, nt = *d_nt;
+    const int tile0 = blockIdx.x * KNN_TILE;
+    if (tile0 >= ns) return;
+    // this block's target range
+    const int chunk = (nt + nsplit - 1) / nsplit;
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(nt, j0 + chunk);
+
+    float sx[KNN_SPT], sy[KNN_SPT], sz[KNN_SPT], bd[KNN_SPT];
+    int bi[KNN_SPT];
+    bool ok[KNN_SPT];
+#pragma unroll
+    for (int k = 0; k < KNN_SPT; ++k) {
+        const int i = tile0 + k * KNN_T + threadIdx.x;
+        ok[k] = i < ns;
+        f3 p{0.0f, 0.0f, 0.0f};
+        if (ok[k]) {
+            p = ld3(src_in, i);
+            if (T) {
+                p = xform(T, p);
+                if (src_out && blockIdx.y == 0) st3(src_out, i, p);
+            }
+        }
+        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
+        bd[k] = INFINITY;
+        bi[k] = 0;
+    }
+    if (j0 >= j1) return;
+    // wave-uniform j: the compiler keeps tgt[j] in SGPRs (s_load), VALU ops read them directly
+    for (int j = j0; j < j1; ++j) {
+        const float tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+#pragma unroll
+        for (int k = 0; k < KNN_SPT; ++k) {
+            const float dx = sx[k] - tx, dy = sy[k] - ty, dz = sz[k] - tz;
+            const float d = (dx * dx + dy * dy) + dz * dz;  // contract off: x->y->z, no fma
+            if (d < bd[k]) { bd[k] = d; bi[k] = j; }        // strict: lowest index wins
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KNN_SPT; ++k) {
+        if (!ok[k] || !(bd[k] < INFINITY)) continue;
+        const int i = tile0 + k * KNN_T + threadIdx.x;
+        const unsigned long long key = ((unsigned long long)fbits(bd[k]) << 32) | (unsigned int)bi[k];
+        atomicMin(best + i, key);
+    }
+}
+
+__global__ void knn_unpack_k(const unsigned long long *__restrict__ best, const int32_t *__restrict__ d_ns,
+                             float *__restrict__ dist2, int64_t *__restrict__ idx) {
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = best[i];
+        if (dist2) dist2[i] = bitsf((uint32_t)(k >> 32));
+        if (idx) idx[i] = (int64_t)(uint32_t)(k & 0xffffffffu);
+    }
+}
+
+__global__ void fill_u64_k(unsigned long long *__restrict__ p, int n, unsigned long long v) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------ J
+struct Row {
+    float a[6], b;
+    bool valid;
+};
+
+// reference odometry/icputils.py:203-230; every product / difference is rounded on its own
+// (elementwise torch ops), so nothing here may fuse.
+__device__ __forceinline__ Row make_row(const float *__restrict__ src, const float *__restrict__ tgt,
+                                        const float *__restrict__ nrm, const unsigned long long *__restrict__ best,
+                                        int i, int ns, float thresh) {
+    Row r;
+    r.valid = false;
+    if (i >= ns) return r;
+    const unsigned long long key = best[i];
+    const uint32_t j = (uint32_t)(key & 0xffffffffu);
+    const float d2 = bitsf((uint32_t)(key >> 32));
+    if (key == ~0ull) return r;                       // no target at all
+    if (thresh >= 0.0f && !(d2 < thresh)) return r;   // NB squared distance vs threshold
+    const f3 s = ld3(src, i), d = ld3(tgt, j), n = ld3(nrm, j);
+    r.a[0] = n.x; r.a[1] = n.y; r.a[2] = n.z;
+    r.a[3] = n.z * s.y - n.y * s.z;
+    r.a[4] = n.x * s.z - n.z * s.x;
+    r.a[5] = n.y * s.x - n.x * s.y;
+    r.b = (n.x * (d.x - s.x) + n.y * (d.y - s.y)) + n.z * (d.z - s.z);
+    r.valid = true;
+    return r;
+}
+
+__global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
+                                                     const float *__restrict__ tgt, const float *__restrict__ nrm,
+                                                     const unsigned long long *__restrict__ best, float thresh,
+                                                     float *__restrict__ partials /* gridDim.x x NACC */) {
+    const int ns = *d_ns;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
+        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
+        if (!r.valid) continue;
+        int q = 0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
+        acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
+        acc[28] += 1.0f;
+    }
+    __shared__ float sm[LIN_T / 64][NACC];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) sm[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < LIN_T / 64; ++w) v += sm[w][threadIdx.x];
+        partials[blockIdx.x * NACC + threadIdx.x] = v;
+    }
+}
+
+// fixed-order reduction of the per-block partials; 64 threads (one wave)
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm /*NACC*/) {
+    const int t = threadIdx.x;
+    if (t < NACC) {
+        float v = 0.0f;
+        for (int b = 0; b < nblocks; ++b) v += partials[b * NACC + t];
+        acc_sm[t] = v;
+    }
+    __syncthreads();
+}
+
+// H (6x6 symmetric) | g | e | cnt from the 29 accumulators
+__device__ __forceinline__ void expand44(const float *acc, float *out44) {
+    int q = 0;
+    for (int u = 0; u < 6; ++u)
+        for (int v = u; v < 6; ++v) { out44[6 * u + v] = acc[q]; out44[6 * v + u] = acc[q]; ++q; }
+    for (int u = 0; u < 6; ++u) out44[36 + u] = acc[21 + u];
+    out44[42] = acc[27];
+    out44[43] = acc[28];
+}
+
+__global__ __launch_bounds__(64) void finalize44_k(const float *__restrict__ partials, int nblocks, float *__restrict__ out44) {
+    __shared__ float acc[NACC];
+    reduce_partials(partials, nblocks, acc);
+    if (threadIdx.x == 0) expand44(acc, out44);
+}
+
+__global__ void icp_rows_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                           const float *__restrict__ nrm, const unsigned long long *__restrict__ best, float thresh,
+                           float *__restrict__ A, float *__restrict__ bvec, uint8_t *__restrict__ keep) {
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
+        keep[i] = r.valid ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) A[6 * (int64_t)i + u] = r.valid ? r.a[u] : 0.0f;
+        bvec[i] = r.valid ? r.b : 0.0f;
+    }
+}
+
+// adjoint of linearize
+__global__ void linearize_bwd_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
+                                const float *__restrict__ tgt, const float *__restrict__ nrm,
+                                const unsigned long long *__restrict__ best, float thresh,
+                                const float *__restrict__ gout /*43: Hbar36 | gbar6 | ebar*/, float *__restrict__ g_src,
+                                float *__restrict__ g_tgt, float *__restrict__ g_nrm) {
+    const int ns = *d_ns;
+    __shared__ float G[43];
+    if (threadIdx.x < 43) G[threadIdx.x] = gout[threadIdx.x];
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
+        if (!r.valid) {
+            if (g_src) st3(g_src, i, f3{0, 0, 0});
+            continue;
+        }
+        const uint32_t j = (uint32_t)(best[i] & 0xffffffffu);
+        const f3 s = ld3(src, i), d = ld3(tgt, j), n = ld3(nrm, j);
+        float ab[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            float v = G[36 + u] * r.b;
+#pragma unroll
+            for (int w = 0; w < 6; ++w) v += (G[6 * u + w] + G[6 * w + u]) * r.a[w];
+            ab[u] = v;
+        }
+        float bb = 2.0f * G[42] * r.b;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) bb += G[36 + u] * r.a[u];
+        // a = [n ; s x n]  (a[3..5] = (n.z s.y - n.y s.z, n.x s.z - n.z s.x, n.y s.x - n.x s.y) = s x n)
+        const f3 an{ab[0], ab[1], ab[2]}, ac{ab[3], ab[4], ab[5]};
+        // c = s x n: s_bar = n x c_bar ; n_bar += c_bar x s
+        f3 sb{n.y * ac.z - n.z * ac.y, n.z * ac.x - n.x * ac.z, n.x * ac.y - n.y * ac.x};
+        f3 nb{an.x + (ac.y * s.z - ac.z * s.y), an.y + (ac.z * s.x - ac.x * s.z), an.z + (ac.x * s.y - ac.y * s.x)};
+        // b = n.(d - s)
+        sb.x -= bb * n.x; sb.y -= bb * n.y; sb.z -= bb * n.z;
+        nb.x += bb * (d.x - s.x); nb.y += bb * (d.y - s.y); nb.z += bb * (d.z - s.z);
+        if (g_src) st3(g_src, i, sb);
+        if (g_tgt) {
+            atomicAdd(g_tgt + 3 * (int64_t)j, bb * n.x);
+            atomicAdd(g_tgt + 3 * (int64_t)j + 1, bb * n.y);
+            atomicAdd(g_tgt + 3 * (int64_t)j + 2, bb * n.z);
+        }
+        if (g_nrm) {
+            atomicAdd(g_nrm + 3 * (int64_t)j, nb.x);
+            atomicAdd(g_nrm + 3 * (int64_t)j + 1, nb.y);
+            atomicAdd(g_nrm + 3 * (int64_t)j + 2, nb.z);
+        }
+    }
+}
+
+__global__ void transform_k(const float *__restrict__ pts, const int32_t *__restrict__ d_n, const float *__restrict__ T,
+                            float *__restrict__ out) {
+    const int n = *d_n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) st3(out, i, xform(T, ld3(pts, i)));
+}
+
+// ------------------------------------------------------------------ X: O(1) algebra on one lane
+// x = (H + damp I)^-1 g.  H, g arrive in fp32 and the damping is added in fp32 like the reference
+// (odometry/icputils.py:86-87); the 6x6 system itself is solved in fp64 with partial pivoting, which
+// removes the solver's own rounding from the parity budget (the reference inverts in fp32 LAPACK).
+__device__ void solve6(const float *H, const float *g, float damp, float *x) {
+    double M[6][7];
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) M[i][j] = (double)(i == j ? H[6 * i + j] + damp : H[6 * i + j]);
+        M[i][6] = (double)g[i];
+    }
+    for (int c = 0; c < 6; ++c) {
+        int p = c;
+        double best = fabs(M[c][c]);
+        for (int r = c + 1; r < 6; ++r)
+            if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+        if (p != c)
+            for (int k = 0; k < 7; ++k) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
+        const double piv = M[c][c];
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = M[r][c] / piv;
+            for (int k = c; k < 7; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    double xs[6];
+    for (int r = 5; r >= 0; --r) {
+        double v = M[r][6];
+        for (int k = r + 1; k < 6; ++k) v -= M[r][k] * xs[k];
+        xs[r] = v / M[r][r];
+    }
+    for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
+}
+
+// reference geometry/se3utils.py:77-115 (xi = [v ; omega]); small-angle branch uses V = I + w^ (sic)
+__device__ void se3_exp_dev(const float *xi, float *T) {
+    const float v0 = xi[0], v1 = xi[1], v2 = xi[2], w0 = xi[3], w1 = xi[4], w2 = xi[5];
+    float Wh[9] = {0.0f, -w2, w1, w2, 0.0f, -w0, -w1, w0, 0.0f};
+    const float th = sqrtf(__fmaf_rn(w2, w2, __fmaf_rn(w1, w1, w0 * w0)));
+    float R[9], V[9];
+    if (th < 1e-6f) {
+        for (int i = 0; i < 9; ++i) { R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + Wh[i]; V[i] = R[i]; }
+    } else {
+        const float s = sinf(th), c = cosf(th);
+        float W2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                W2[3 * i + j] = dot3_fma(Wh[3 * i], Wh[3 * i + 1], Wh[3 * i + 2], Wh[j], Wh[3 + j], Wh[6 + j]);
+        const float A = s / th, Bc = (1.0f - c) / (th * th), C = (th - s) / (th * th * th);
+        for (int i = 0; i < 9; ++i) {
+            const float e = (i % 4 == 0) ? 1.0f : 0.0f;
+            R[i] = (e + A * Wh[i]) + Bc * W2[i];
+            V[i] = (e + Bc * Wh[i]) + C * W2[i];
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        T[4 * i] = R[3 * i]; T[4 * i + 1] = R[3 * i + 1]; T[4 * i + 2] = R[3 * i + 2];
+        T[4 * i + 3] = dot3_fma(V[3 * i], V[3 * i + 1], V[3 * i + 2], v0, v1, v2);
+    }
+    T[12] = 0.0f; T[13] = 0.0f; T[14] = 0.0f; T[15] = 1.0f;
+}
+
+// C = A . B for 4x4 (torch.mm contraction: fma chain over k)
+__device__ void mm4(const float *A, const float *B, float *C) {
+    float r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float v = A[4 * i] * B[j];
+            v = __fmaf_rn(A[4 * i + 1], B[4 + j], v);
+            v = __fmaf_rn(A[4 * i + 2], B[8 + j], v);
+            v = __fmaf_rn(A[4 * i + 3], B[12 + j], v);
+            r[4 * i + j] = v;
+        }
+    for (int i = 0; i < 16; ++i) C[i] = r[i];
+}
+
+// Device-resident loop state.  Two source-cloud buffers / NN buffers ping-pong; `sel` says which
+// one is the current cloud.
+struct IcpState {
+    float T[16];      // accumulated transform
+    float dT[16];     // step handed to the next association launch
+    float cur[44];    // H|g|e|cnt of the current cloud
+    float xi[6];
+    float damp;
+    int sel;          // current cloud = buf[sel]
+    int sel_first;    // buffer that held the cloud of the last iteration's first solve
+    int it;
+};
+
+enum StepMode { STEP_INIT = 0, STEP_LM = 1, STEP_GRAD_A = 2, STEP_GRAD_B = 3 };
+
+struct GradParams {
+    // formed in double on the host like the reference's Python scalars, rounded once:
+    // lambda_min = 1/lambda_max, range = lambda_max - lambda_min, inv_nu = 1/nu
+    float lambda_min, range, B, B2, inv_nu;
+};
+
+// One wave.  Reduces the partials of the association+linearise launch that just ran and advances
+// the LM / gradLM state machine; fills best[] of the buffer the NEXT launch will write with the
+// all-ones key.
+//   STEP_INIT  : partials describe the initial cloud      -> cur = lin ; solve ; dT = exp(xi)
+//   STEP_LM    : partials describe the look-ahead cloud   -> accept/reject ; solve ; dT = exp(xi)
+//   STEP_GRAD_A: partials describe the current cloud      -> cur = lin ; solve ; dT = exp(xi)
+//   STEP_GRAD_B: partials describe the look-ahead cloud   -> damp, sigma ; dT = exp(sigma xi) ; T = dT T
+__global__ __launch_bounds__(64) void icp_step_k(IcpState *__restrict__ S, const float *__restrict__ partials, int nblocks,
+                                                 int mode, int last, GradParams gp, float *__restrict__ trace /* or NULL */,
+                                                 unsigned long long *__restrict__ bestA,
+                                                 unsigned long long *__restrict__ bestB, int max_ns,
+                                                 float *__restrict__ out_T /* or NULL: written every step */) {
+    __shared__ float acc[NACC];
+    __shared__ int s_next_fill;
+    reduce_partials(partials, nblocks, acc);
+    if (threadIdx.x == 0) {
+        float lin[44];
+        expand44(acc, lin);
+        int fill = -1;  // which best buffer the next association launch writes
+        if (mode == STEP_INIT || mode == STEP_GRAD_A) {
+            for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
+            solve6(S->cur, S->cur + 36, S->damp, S->xi);
+            se3_exp_dev(S->xi, S->dT);
+            S->sel_first = S->sel;
+            fill = 1 - S->sel;  // look-ahead goes to the other buffer
+        } else if (mode == STEP_LM) {
+            const float err = S->cur[42], new_err = lin[42];
+            const bool accept = new_err < err;
+            if (trace) {
+                float *t = trace + 48 * S->it;
+                for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
+                t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = accept ? 1.0f : 0.0f; t[46] = S->cur[43];
+                t[47] = 0.0f;
+            }
+            S->sel_first = S->sel;
+            if (accept) {
+                S->sel = 1 - S->sel;
+                for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
+                S->damp = S->damp / 2.0f;
+                mm4(S->dT, S->T, S->T);
+            } else {
+                S->damp = S->damp * 2.0f;
+            }
+            S->it += 1;
+            solve6(S->cur, S->cur + 36, S->damp, S->xi);
+            se3_exp_dev(S->xi, S->dT);
+            fill = 1 - S->sel;
+        } else {  // STEP_GRAD_B
+            const float err = S->cur[42], new_err = lin[42];
+            float diff = new_err - err;
+            diff = fminf(fmaxf(diff, -70.0f), 70.0f);
+            const float damp_new = gp.lambda_min + gp.range / (1.0f + expf((-gp.B) * diff));
+            if (trace) {
+                float *t = trace + 48 * S->it;
+                for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
+                t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = 1.0f; t[46] = S->cur[43]; t[47] = 0.0f;
+            }
+            S->damp = S->damp * damp_new;
+            const float sig = 1.0f / powf(1.0f + expf((-gp.B2) * diff), gp.inv_nu);
+            float sx[6];
+            for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
+            se3_exp_dev(sx, S->dT);
+            mm4(S->dT, S->T, S->T);
+            S->it += 1;
+            // the next launch transforms buf[sel] by dT into buf[1-sel] and that becomes current
+            fill = 1 - S->sel;
+            S->sel = 1 - S->sel;
+        }
+        if (out_T)
+            for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
+        s_next_fill = last ? -1 : fill;  // nothing follows the last step: keep every NN buffer intact
+    }
+    __syncthreads();
+    if (s_next_fill >= 0) {
+        unsigned long long *dst = (s_next_fill == 0) ? bestA : bestB;
+        for (int i = threadIdx.x; i < max_ns; i += 64) dst[i] = ~0ull;
+    }
+}
+
+__global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, float damp) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 16; ++i) { S->T[i] = init_T[i]; S->dT[i] = init_T[i]; }
+        S->damp = damp;
+        S->sel = 0;  // the first association launch writes buf[0] = init_T . src
+        S->sel_first = 0;
+        S->it = 0;
+    }
+}
+
+// association launch parameterised by the device-side selector: reads buf[in_sel] (or the user's
+// src for the very first launch), writes buf[out] .
+__global__ __launch_bounds__(KNN_T) void knn1_sel_k(const IcpState *__restrict__ S, int first, const float *__restrict__ user_src,
+                                                    float *__restrict__ bufA, float *__restrict__ bufB,
+                                                    const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                                                    const int32_t *__restrict__ d_nt, int nsplit,
+                                                    unsigned long long *__restrict__ bestA,
+                                                    unsigned long long *__restrict__ bestB, int grad_mode_b) {
+    // first launch: in = user src, T = init_T (held in S->dT), out = buf[0]
+    // LM look-ahead / grad pass B: in = buf[sel], T = dT, out = buf[1-sel]
+    // grad pass A (after STEP_GRAD_B flipped sel): in = buf[1-sel], T = dT, out = buf[sel]
+    const int sel = S->sel;
+    const float *in;
+    float *out;
+    unsigned long long *best;
+    if (first) {
+        in = user_src; out = bufA; best = bestA;
+    } else if (grad_mode_b == 2) {  // pass A of gradICP iterations > 0
+        in = sel ? bufA : bufB; out = sel ? bufB : bufA; best = sel ? bestB : bestA;
+    } else {
+        in = sel ? bufB : bufA; out = sel ? bufA : bufB; best = sel ? bestA : bestB;
+    }
+    const int ns = *d_ns, nt = *d_nt;
+    const int tile0 = blockIdx.x * KNN_TILE;
+    if (tile0 >= ns) return;
+    const int chunk = (nt + nsplit - 1) / nsplit;
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(nt, j0 + chunk);
+    const float *T = S->dT;
+    float sx[KNN_SPT], sy[KNN_SPT], sz[KNN_SPT], bd[KNN_SPT];
+    int bi[KNN_SPT];
+    bool ok[KNN_SPT];
+#pragma unroll
+    for (int k = 0; k < KNN_SPT; ++k) {
+        const int i = tile0 + k * KNN_T + threadIdx.x;
+        ok[k] = i < ns;
+        f3 p{0.0f, 0.0f, 0.0f};
+        if (ok[k]) {
+            p = xform(T, ld3(in, i));
+            if (blockIdx.y == 0) st3(out, i, p);
+        }
+        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
+        bd[k] = INFINITY;
+        bi[k] = 0;
+    }
+    if (j0 >= j1) return;
+    for (int j = j0; j < j1; ++j) {
+        const float tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+#pragma unroll
+        for (int k = 0; k < KNN_SPT; ++k) {
+            const float dx = sx[k] - tx, dy = sy[k] - ty, dz = sz[k] - tz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d < bd[k]) { bd[k] = d; bi[k] = j; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KNN_SPT; ++k) {
+        if (!ok[k] || !(bd[k] < INFINITY)) continue;
+        const int i = tile0 + k * KNN_T + threadIdx.x;
+        atomicMin(best + i, ((unsigned long long)fbits(bd[k]) << 32) | (unsigned int)bi[k]);
+    }
+}
+
+// linearise the cloud the association launch above just produced (same selector logic)
+__global__ __launch_bounds__(LIN_T) void linearize_sel_k(const IcpState *__restrict__ S, int first, const float *__restrict__ bufA,
+                                                         const float *__restrict__ bufB, const int32_t *__restrict__ d_ns,
+                                                         const float *__restrict__ tgt, const float *__restrict__ nrm,
+                                                         const unsigned long long *__restrict__ bestA,
+                                                         const unsigned long long *__restrict__ bestB, float thresh,
+                                                         int grad_mode_b, float *__restrict__ partials) {
+    const int sel = S->sel;
+    const float *src;
+    const unsigned long long *best;
+    if (first) { src = bufA; best = bestA; }
+    else if (grad_mode_b == 2) { src = sel ? bufB : bufA; best = sel ? bestB : bestA; }
+    else { src = sel ? bufA : bufB; best = sel ? bestA : bestB; }
+    const int ns = *d_ns;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
+        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
+        if (!r.valid) continue;
+        int q = 0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
+        acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
+        acc[28] += 1.0f;
+    }
+    __shared__ float sm[LIN_T / 64][NACC];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) sm[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < LIN_T / 64; ++w) v += sm[w][threadIdx.x];
+        partials[blockIdx.x * NACC + threadIdx.x] = v;
+    }
+}
+
+__global__ void copy_best_last_k(const IcpState *__restrict__ S, const unsigned long long *__restrict__ bestA,
+                                 const unsigned long long *__restrict__ bestB, const int32_t *__restrict__ d_ns,
+                                 unsigned long long *__restrict__ out) {
+    const unsigned long long *src = S->sel_first ? bestB : bestA;
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) out[i] = src[i];
+}
+
+static inline int knn_nsplit(int max_ns, int max_nt) {
+    const int tiles = cdiv(max_ns, KNN_TILE);
+    int ns = cdiv(2048, tiles);
+    const int cap = cdiv(max_nt, 64);
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    if (ns > 4096) ns = 4096;
+    return ns;
+}
+static inline int lin_blocks(int max_ns) {
+    int nb = cdiv(max_ns, LIN_T);
+    if (nb > LIN_MAXB) nb = LIN_MAXB;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+struct IcpWs {
+    IcpState *S;
+    float *bufA, *bufB;
+    unsigned long long *bestA, *bestB;
+    float *partials;
+};
+static inline size_t icp_ws_layout(int max_ns, void *ws, IcpWs *out) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t oS = take(sizeof(IcpState));
+    const size_t oA = take((size_t)max_ns * 12), oB = take((size_t)max_ns * 12);
+    const size_t obA = take((size_t)max_ns * 8), obB = take((size_t)max_ns * 8);
+    const size_t oP = take((size_t)LIN_MAXB * NACC * 4);
+    if (ws && out) {
+        char *p = (char *)ws;
+        out->S = (IcpState *)(p + oS);
+        out->bufA = (float *)(p + oA); out->bufB = (float *)(p + oB);
+        out->bestA = (unsigned long long *)(p + obA); out->bestB = (unsigned long long *)(p + obB);
+        out->partials = (float *)(p + oP);
+    }
+    return off;
+}
+
+static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
+                   const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp, float thresh,
+                   GradParams gp, float *out_T, uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
+                   hipStream_t st, const char *name) {
+    GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && init_T && out_T, "%s: NULL argument", name);
+    GS_REQUIRE(max_ns > 0 && max_nt > 0 && numiters >= 0, "%s: bad sizes max_ns=%d max_nt=%d numiters=%d", name, max_ns, max_nt, numiters);
+    if (!ws || ws_bytes < icp_ws_layout(max_ns, nullptr, nullptr)) {
+        set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, icp_ws_layout(max_ns, nullptr, nullptr));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    IcpWs w;
+    icp_ws_layout(max_ns, ws, &w);
+    const int nsplit = knn_nsplit(max_ns, max_nt);
+    const dim3 kgrid(cdiv(max_ns, KNN_TILE), nsplit);
+    const int lb = lin_blocks(max_ns);
+    const int fb = min(cdiv(max_ns, 256), 256);
+
+    hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
+    hipLaunchKernelGGL(fill_u64_k, dim3(fb), dim3(256), 0, st, w.bestA, max_ns, ~0ull);
+    GS_LAUNCH_CHECK(name);
+    if (numiters == 0) {
+        GS_HIP(hipMemcpyAsync(out_T, init_T, 64, hipMemcpyDeviceToDevice, st), name);
+        return GS_OK;
+    }
+    auto assoc = [&](int first, int gm) {
+        hipLaunchKernelGGL(knn1_sel_k, kgrid, dim3(KNN_T), 0, st, w.S, first, src, w.bufA, w.bufB, d_ns, tgt, d_nt, nsplit,
+                           w.bestA, w.bestB, gm);
+        hipLaunchKernelGGL(linearize_sel_k, dim3(lb), dim3(LIN_T), 0, st, w.S, first, w.bufA, w.bufB, d_ns, tgt, nrm,
+                           w.bestA, w.bestB, thresh, gm, w.partials);
+    };
+    auto step = [&](int mode, int last) {
+        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(64), 0, st, w.S, w.partials, lb, mode, last, gp, trace, w.bestA,
+                           w.bestB, max_ns, out_T);
+    };
+    if (!grad) {
+        // numiters + 1 associations instead of the reference's 2 x numiters: an accepted look-ahead
+        // IS the next iteration's first linearisation, a rejected one leaves it unchanged.
+        assoc(1, 0);
+        step(STEP_INIT, 0);
+        for (int it = 0; it < numiters; ++it) {
+            assoc(0, 0);
+            step(STEP_LM, it + 1 == numiters);
+        }
+    } else {
+        assoc(1, 0);
+        step(STEP_GRAD_A, 0);
+        for (int it = 0; it < numiters; ++it) {
+            assoc(0, 1);                              // look-ahead: buf[sel] . dT -> buf[1-sel]
+            step(STEP_GRAD_B, it + 1 == numiters);    // dT = exp(sigma xi); flips sel
+            if (it + 1 < numiters) {
+                assoc(0, 2);                          // current cloud: buf[1-sel] . dT -> buf[sel]
+                step(STEP_GRAD_A, 0);
+            }
+        }
+    }
+    GS_LAUNCH_CHECK(name);
+    if (best_last) {
+        hipLaunchKernelGGL(copy_best_last_k, dim3(fb), dim3(256), 0, st, w.S, w.bestA, w.bestB, d_ns,
+                           (unsigned long long *)best_last);
+        GS_LAUNCH_CHECK(name);
+    }
+    return GS_OK;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const int32_t *d_nt, int max_nt,
+            uint64_t *best, gs_stream_t stream) {
+    GS_REQUIRE(src && d_ns && tgt && d_nt && best, "gs_knn1: NULL argument");
+    GS_REQUIRE(max_ns >= 0 && max_nt >= 0, "gs_knn1: negative size");
+    if (max_ns == 0) return GS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_u64_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, st, (unsigned long long *)best, max_ns, ~0ull);
+    GS_LAUNCH_CHECK("gs_knn1/fill");
+    if (max_nt == 0) return GS_OK;
+    const int nsplit = knn_nsplit(max_ns, max_nt);
+    hipLaunchKernelGGL(knn1_k, dim3(cdiv(max_ns, KNN_TILE), nsplit), dim3(KNN_T), 0, st, src, d_ns, (const float *)nullptr,
+                       (float *)nullptr, tgt, d_nt, nsplit, (unsigned long long *)best);
+    GS_LAUNCH_CHECK("gs_knn1");
+    return GS_OK;
+}
+
+int gs_knn1_unpack(const uint64_t *best, const int32_t *d_ns, int max_ns, float *dist2, int64_t *idx, gs_stream_t stream) {
+    GS_REQUIRE(best && d_ns && max_ns >= 0, "gs_knn1_unpack: bad arguments");
+    if (max_ns == 0) return GS_OK;
+    hipLaunchKernelGGL(knn_unpack_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long *)best, d_ns, dist2, idx);
+    GS_LAUNCH_CHECK("gs_knn1_unpack");
+    return GS_OK;
+}
+
+size_t gs_icp_linearize_ws_bytes(int max_ns) { (void)max_ns; return align_up((size_t)LIN_MAXB * NACC * 4, 256); }
+
+int gs_icp_linearize(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
+                     const uint64_t *best, float dist_thresh, float *out44, void *ws, size_t ws_bytes,
+                     gs_stream_t stream) {
+    GS_REQUIRE(src && d_ns && tgt && tgt_normals && best && out44, "gs_icp_linearize: NULL argument");
+    GS_REQUIRE(max_ns >= 0, "gs_icp_linearize: negative size");
+    if (!ws || ws_bytes < gs_icp_linearize_ws_bytes(max_ns)) {
+        set_error("gs_icp_linearize: workspace too small");
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // large clouds: several points per thread, grid capped so the partial tree stays two-level
+    int nb = cdiv(max_ns, LIN_T * 4);
+    if (nb < lin_blocks(max_ns) && max_ns <= LIN_T * LIN_MAXB) nb = lin_blocks(max_ns);
+    if (nb > LIN_MAXB) nb = LIN_MAXB;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(linearize_k, dim3(nb), dim3(LIN_T), 0, st, src, d_ns, tgt, tgt_normals,
+                       (const unsigned long long *)best, dist_thresh, (float *)ws);
+    GS_LAUNCH_CHECK("gs_icp_linearize");
+    hipLaunchKernelGGL(finalize44_k, dim3(1), dim3(64), 0, st, (const float *)ws, nb, out44);
+    GS_LAUNCH_CHECK("gs_icp_linearize/finalize");
+    return GS_OK;
+}
+
+int gs_icp_rows(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
+                const uint64_t *best, float dist_thresh, float *A, float *b, uint8_t *keep, gs_stream_t stream) {
+    GS_REQUIRE(src && d_ns && tgt && tgt_normals && best && A && b && keep, "gs_icp_rows: NULL argument");
+    if (max_ns <= 0) return GS_OK;
+    hipLaunchKernelGGL(icp_rows_k, dim3(min(cdiv(max_ns, 256), 2048)), dim3(256), 0, (hipStream_t)stream, src, d_ns, tgt,
+                       tgt_normals, (const unsigned long long *)best, dist_thresh, A, b, keep);
+    GS_LAUNCH_CHECK("gs_icp_rows");
+    return GS_OK;
+}
+
+int gs_icp_linearize_backward(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                              const float *tgt_normals, const uint64_t *best, float dist_thresh, const float *g_out43,
+                              float *g_src, float *g_tgt, float *g_normals, gs_stream_t stream) {
+    GS_REQUIRE(src && d_ns && tgt && tgt_normals && best && g_out43, "gs_icp_linearize_backward: NULL argument");
+    if (max_ns <= 0) return GS_OK;
+    hipLaunchKernelGGL(linearize_bwd_k, dim3(min(cdiv(max_ns, 256), 2048)), dim3(256), 0, (hipStream_t)stream, src, d_ns,
+                       tgt, tgt_normals, (const unsigned long long *)best, dist_thresh, g_out43, g_src, g_tgt, g_normals);
+    GS_LAUNCH_CHECK("gs_icp_linearize_backward");
+    return GS_OK;
+}
+
+int gs_transform_points(const float *pts, const int32_t *d_n, int max_n, const float *T, float *out, gs_stream_t stream) {
+    GS_REQUIRE(pts && d_n && T && out && max_n >= 0, "gs_transform_points: bad arguments");
+    if (max_n == 0) return GS_OK;
+    hipLaunchKernelGGL(transform_k, dim3(min(cdiv(max_n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, pts, d_n, T, out);
+    GS_LAUNCH_CHECK("gs_transform_points");
+    return GS_OK;
+}
+
+size_t gs_icp_ws_bytes(int max_ns) { return icp_ws_layout(max_ns > 0 ? max_ns : 1, nullptr, nullptr); }
+
+int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
+                          const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp,
+                          float dist_thresh, float *out_T, uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
+                          gs_stream_t stream) {
+    return icp_run(false, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, damp, dist_thresh,
+                   GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f}, out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream,
+                   "gs_icp_point_to_plane");
+}
+
+int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                               const float *tgt_normals, const int32_t *d_nt, int max_nt, const float *init_T,
+                               int numiters, float damp, float dist_thresh, float lambda_max, float B, float B2, float nu,
+                               float *out_T, uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
+                               gs_stream_t stream) {
+    return icp_run(true, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, damp, dist_thresh,
+                   GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max), B, B2,
+                              (float)(1.0 / (double)nu)},
+                   out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream,
+                   "gs_icp_point_to_plane_grad");
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// project.hip -- active-map-point search (P) and the map-side downsample gather (S).
+//
+// HBM-bound stream over the map: 12 B read per map point, 32 B written per active row.  The
+// projection is evaluated twice (count pass + write pass) instead of staging flags: the second
+// read of the points is served by L2 / Infinity Cache and costs less than a 4 B/pt flag round trip.
+#include "gs_common.hpp"
+#include "gs_compact.hpp"
+
+namespace gs {
+
+struct Cam {
+    float R[9];     // camera pose rotation (world <- cam), row-major
+    float tinv[3];  // -R^T t
+    float K[16];
+};
+
+// One Cam per batch element, computed on device (no host math, no sync).
+// inverse_transformation semantics (R^T, -R^T t); the small batched matmul(-R^T, t) does not fuse.
+__global__ void build_cams_k(const float *__restrict__ poses, const float *__restrict__ Ks, int B, Cam *__restrict__ cams) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *T = poses + 16 * b;
+    Cam c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.R[3 * i + j] = T[4 * i + j];
+    const float t0 = T[3], t1 = T[7], t2 = T[11];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // row j of -R^T is (-R[0][j], -R[1][j], -R[2][j])
+        c.tinv[j] = ((-T[j]) * t0 + (-T[4 + j]) * t1) + (-T[8 + j]) * t2;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c.K[i] = Ks[16 * b + i];
+    cams[b] = c;
+}
+
+// Projects map point p of batch element with camera c.  Returns true iff the point is active and
+// fills (h, w).  reference slam/fusionutils.py:250-274, structures/pointclouds.py:501-517,423-425,
+// geometry/projutils.py:221-236.
+__device__ __forceinline__ bool project_point(const Cam &c, f3 p, int H, int W, float umax, float vmax, int &h, int &w) {
+    // p' = p . Rinv^T + tinv, Rinv^T == R: p'_k = sum_j p_j R[j][k]   (GEMM contraction)
+    const float x = dot3_fma(p.x, p.y, p.z, c.R[0], c.R[3], c.R[6]) + c.tinv[0];
+    const float y = dot3_fma(p.x, p.y, p.z, c.R[1], c.R[4], c.R[7]) + c.tinv[1];
+    const float z = dot3_fma(p.x, p.y, p.z, c.R[2], c.R[5], c.R[8]) + c.tinv[2];
+    const bool front = z > 0.0f;
+    // K4x4 . [p',1]: broadcast batched 4x4 @ 4x1 -> plain (unfused) accumulation
+    const float *K = c.K;
+    const float qx = ((K[0] * x + K[1] * y) + K[2] * z) + K[3] * 1.0f;
+    const float qy = ((K[4] * x + K[5] * y) + K[6] * z) + K[7] * 1.0f;
+    const float qz = ((K[8] * x + K[9] * y) + K[10] * z) + K[11] * 1.0f;
+    const float zs = (qz != 0.0f) ? qz : 1.0f;
+    const float u = qx / zs, v = qy / zs;
+    // umax = fp32(W - 0.999), vmax = fp32(H - 0.999): formed in double on the host like the reference's
+    // Python scalars, then rounded once
+    const bool in = (u > -1e-3f) && (u < umax) && (v > -1e-3f) && (v < vmax) && front;
+    // round-half-to-even like torch.round; clamp like .clamp(0, H-1)
+    const float ru = rintf(u), rv = rintf(v);
+    w = (int)fminf(fmaxf(ru, 0.0f), (float)(W - 1));
+    h = (int)fminf(fmaxf(rv, 0.0f), (float)(H - 1));
+    return in;
+}
+
+struct ActivePred {
+    const float *points;
+    const int32_t *counts;
+    const Cam *cams;
+    int Nmax, H, W, ds;
+    float umax, vmax;
+    __device__ bool operator()(int64_t i) const {
+        const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
+        if (n >= counts[b]) return false;
+        int h, w;
+        if (!project_point(cams[b], ld3(points, i), H, W, umax, vmax, h, w)) return false;
+        return ds <= 0 || ((h % ds == 0) && (w % ds == 0));
+    }
+};
+struct ActiveWriter {
+    const float *points;
+    const Cam *cams;
+    int64_t *rows;
+    int Nmax, H, W;
+    float umax, vmax;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
+        int h, w;
+        project_point(cams[b], ld3(points, i), H, W, umax, vmax, h, w);
+        longlong4 r;  // one 32-byte store per row
+        r.x = b; r.y = n; r.z = h; r.w = w;
+        *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
+    }
+};
+
+// starts[b] = first table row with row.b >= b (rows sorted by b); starts[B] = n_rows
+__global__ void table_starts_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n, int B, int32_t *__restrict__ starts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    const int n = *d_n;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (rows[4 * (int64_t)mid] < b) lo = mid + 1; else hi = mid;
+    }
+    starts[b] = lo;
+}
+
+__global__ void gather_table_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
+                               const int32_t *__restrict__ starts, const float *__restrict__ attr, int B, int Nmax, int C,
+                               int cap, float *__restrict__ out, int32_t *__restrict__ counts) {
+    const int n = *d_n;
+    if (blockIdx.x == 0 && threadIdx.x < B && counts) counts[threadIdx.x] = starts[threadIdx.x + 1] - starts[threadIdx.x];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)rows[4 * i], p = (int)rows[4 * i + 1];
+        const int k = (int)(i - starts[b]);
+        if (k >= cap) continue;
+        const float *s = attr + ((int64_t)b * Nmax + p) * C;
+        float *d = out + ((int64_t)b * cap + k) * C;
+        for (int c = 0; c < C; ++c) d[c] = s[c];
+    }
+}
+
+__global__ void table_ds_mask_k(const int64_t *__restrict__ rows, int64_t n, int ds, uint8_t *__restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = ((rows[4 * i + 2] % ds) == 0 && (rows[4 * i + 3] % ds) == 0) ? 1 : 0;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+size_t gs_project_active_ws_bytes(int B, int Nmax) {
+    return align_up(sizeof(Cam) * (size_t)(B > 0 ? B : 1), 256) + compact_ws_bytes((int64_t)B * Nmax);
+}
+
+int gs_project_active(const float *points, const int32_t *counts, int B, int Nmax, const float *poses,
+                      const float *intrinsics, int H, int W, int ds, int64_t *out_rows, int32_t *out_count, void *ws,
+                      size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(points && counts && poses && intrinsics && out_rows && out_count, "gs_project_active: NULL argument");
+    GS_REQUIRE(B > 0 && Nmax > 0 && H > 0 && W > 0, "gs_project_active: bad shape B=%d Nmax=%d H=%d W=%d", B, Nmax, H, W);
+    if (!ws || ws_bytes < gs_project_active_ws_bytes(B, Nmax)) {
+        set_error("gs_project_active: workspace too small (%zu < %zu)", ws_bytes, gs_project_active_ws_bytes(B, Nmax));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    Cam *cams = (Cam *)ws;
+    void *cws = (char *)ws + align_up(sizeof(Cam) * (size_t)B, 256);
+    hipLaunchKernelGGL(build_cams_k, dim3(cdiv(B, 64)), dim3(64), 0, st, poses, intrinsics, B, cams);
+    GS_LAUNCH_CHECK("gs_project_active/cams");
+    const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
+    ActivePred pred{points, counts, cams, Nmax, H, W, ds, umax, vmax};
+    ActiveWriter wr{points, cams, out_rows, Nmax, H, W, umax, vmax};
+    return compact_launch((int64_t)B * Nmax, pred, wr, out_count, cws, st, "gs_project_active");
+}
+
+size_t gs_gather_table_rows_ws_bytes(int B) { return align_up(sizeof(int32_t) * (size_t)(B + 1), 256); }
+
+int gs_gather_table_rows(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, const float *attr, int B,
+                         int Nmax, int C, int cap, float *out, int32_t *counts, void *ws, size_t ws_bytes,
+                         gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && attr && out, "gs_gather_table_rows: NULL argument");
+    GS_REQUIRE(B > 0 && B <= 256 && Nmax > 0 && C > 0 && cap >= 0 && max_rows >= 0, "gs_gather_table_rows: bad shape (B <= 256)");
+    if (!ws || ws_bytes < gs_gather_table_rows_ws_bytes(B)) {
+        set_error("gs_gather_table_rows: workspace too small");
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *starts = (int32_t *)ws;
+    hipLaunchKernelGGL(table_starts_k, dim3(cdiv(B + 1, 64)), dim3(64), 0, st, rows, d_n_rows, B, starts);
+    GS_LAUNCH_CHECK("gs_gather_table_rows/starts");
+    const int nb = max_rows > 0 ? min(cdiv(max_rows, 256), 2048) : 1;
+    hipLaunchKernelGGL(gather_table_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, attr, B, Nmax,
+                       C, cap, out, counts);
+    GS_LAUNCH_CHECK("gs_gather_table_rows");
+    return GS_OK;
+}
+
+int gs_table_ds_mask(const int64_t *rows, int64_t n_rows, int ds, uint8_t *mask, gs_stream_t stream) {
+    GS_REQUIRE(rows && mask && n_rows >= 0 && ds > 0, "gs_table_ds_mask: bad arguments");
+    if (n_rows == 0) return GS_OK;
+    hipLaunchKernelGGL(table_ds_mask_k, dim3(min(cdiv(n_rows, 256), 2048)), dim3(256), 0, (hipStream_t)stream, rows,
+                       n_rows, ds, mask);
+    GS_LAUNCH_CHECK("gs_table_ds_mask");
+    return GS_OK;
+}
+
+}  // extern "C"

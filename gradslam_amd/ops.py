@@ -1,0 +1,447 @@
+"""Tensor-level front of the C ABI: one Python function per kernel family, plus the
+`torch.autograd.Function`s that keep the reference's gradients flowing through them.
+
+Nothing here computes on the CPU.  Tensors must live on a HIP device (`require_hip`).
+Shapes follow the reference: images channels-last (B,L,H,W,C), clouds padded (B,N,C), tables
+(P,4) int64 rows [b,n,h,w].
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nv
+from ._native import call, ptr, require_hip, stream, workspace, ws_bytes
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def dev_int(value: int, device) -> torch.Tensor:
+    """A device-resident int32 scalar (filled by a kernel: no host->device copy, no sync)."""
+    return torch.full((1,), int(value), dtype=torch.int32, device=device)
+
+
+# ---------------------------------------------------------------------------------------------- V
+def vertex_normal_maps_raw(depth, K, poses, want_local=True, want_global=True):
+    """depth (B,L,H,W,1), K (B,1,4,4), poses (B,L,4,4) or None -> (V, N, gV, gN); entries not
+    requested are None.  One fused launch (reference structures/rgbdimages.py:643-762)."""
+    require_hip(depth, K, poses, op="vertex_normal_maps")
+    depth, K, poses = _f32c(depth), _f32c(K), _f32c(poses)
+    B, L, H, W = depth.shape[:4]
+    mk = lambda: torch.empty((B, L, H, W, 3), dtype=torch.float32, device=depth.device)
+    V = mk() if want_local else None
+    N = mk() if want_local else None
+    gV = mk() if want_global else None
+    gN = mk() if want_global else None
+    call("gs_vertex_normal_maps", ptr(depth), ptr(K), ptr(poses), B, L, H, W, ptr(V), ptr(N), ptr(gV), ptr(gN), stream())
+    return V, N, gV, gN
+
+
+class _MapsFn(torch.autograd.Function):
+    """(depth, K, poses) -> (V, N, gV, gN) with the hand-written adjoint."""
+
+    @staticmethod
+    def forward(ctx, depth, K, poses, want_local, want_global):
+        V, N, gV, gN = vertex_normal_maps_raw(depth, K, poses, want_local, want_global)
+        ctx.save_for_backward(depth, K, poses)
+        ctx.has_poses = poses is not None
+        dummy = depth.new_empty(0)
+        outs = tuple(x if x is not None else dummy for x in (V, N, gV, gN))
+        ctx.mark_non_differentiable(*[o for o, x in zip(outs, (V, N, gV, gN)) if x is None])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gV_l, gN_l, gV_g, gN_g):
+        depth, K, poses = ctx.saved_tensors
+        depth_c, K_c, poses_c = _f32c(depth), _f32c(K), _f32c(poses)
+        B, L, H, W = depth.shape[:4]
+        fix = lambda g: None if (g is None or g.numel() == 0) else _f32c(g)
+        gV_l, gN_l, gV_g, gN_g = fix(gV_l), fix(gN_l), fix(gV_g), fix(gN_g)
+        g_depth = torch.zeros_like(depth_c)
+        g_K = torch.zeros_like(K_c)
+        g_P = torch.zeros_like(poses_c) if poses_c is not None else None
+        nb = ws_bytes("gs_vertex_normal_maps_backward_ws_bytes", B, L, H, W)
+        ws = workspace(nb, depth.device, "maps_bwd")
+        call("gs_vertex_normal_maps_backward", ptr(depth_c), ptr(K_c), ptr(poses_c), B, L, H, W, ptr(gV_l), ptr(gN_l),
+             ptr(gV_g), ptr(gN_g), ptr(g_depth), ptr(g_K), ptr(g_P), ptr(ws), ws.numel(), stream())
+        return g_depth.view_as(depth), g_K.view_as(K), (g_P.view_as(poses) if g_P is not None else None), None, None
+
+
+def vertex_normal_maps(depth, K, poses, want_local=True, want_global=True):
+    """Autograd-aware entry: returns (V, N, gV, gN) (None where not requested)."""
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (depth, K, poses))
+    if not needs_grad:
+        return vertex_normal_maps_raw(depth, K, poses, want_local, want_global)
+    outs = _MapsFn.apply(depth, K, poses, want_local, want_global)
+    sel = (want_local, want_local, want_global, want_global)
+    return tuple(o if s else None for o, s in zip(outs, sel))
+
+
+# ---------------------------------------------------------------------------------------------- alpha
+class _AlphaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, sigma, eps):
+        p = _f32c(pts)
+        out = torch.empty(p.shape[:-1], dtype=torch.float32, device=p.device)
+        call("gs_get_alpha", ptr(p), p.numel() // 3, float(sigma), float(eps), ptr(out), stream())
+        ctx.save_for_backward(p)
+        ctx.sigma, ctx.eps = float(sigma), float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        gp = torch.zeros_like(p)
+        call("gs_get_alpha_backward", ptr(p), p.numel() // 3, ctx.sigma, ctx.eps, ptr(_f32c(g)), ptr(gp), stream())
+        return gp, None, None
+
+
+def get_alpha_lastdim(points: torch.Tensor, sigma: float, eps: float) -> torch.Tensor:
+    """points (..., 3) -> alpha (...)  (reference slam/fusionutils.py:69-73)."""
+    require_hip(points, op="get_alpha")
+    return _AlphaFn.apply(points, sigma, eps)
+
+
+# ---------------------------------------------------------------------------------------------- compaction
+def compact_rows(src: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """src (n, C) float32 or (n, C) int64, mask (n,) bool/uint8 -> src[mask], order preserved.
+    One host sync to learn the output length."""
+    require_hip(src, mask, op="compact_rows")
+    n = src.shape[0]
+    src = src.contiguous()
+    m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
+    words = (src.element_size() * (src.numel() // max(n, 1))) // 4 if n else 0
+    out = torch.empty_like(src)
+    cnt = torch.zeros(1, dtype=torch.int32, device=src.device)
+    ws = workspace(ws_bytes("gs_compact_ws_bytes", n), src.device, "compact")
+    call("gs_compact_rows", ptr(src), ptr(m8), n, words, ptr(out), ptr(cnt), ptr(ws), ws.numel(), stream())
+    return out[: int(cnt.item())]
+
+
+def compact_multi_raw(srcs, mask):
+    """srcs: list of <=4 (n, C_a) float32 tensors sharing `mask` (n,) uint8/bool -> (list of (n, C_a)
+    output buffers, count (1,) int32 device).  No sync; rows beyond count are garbage."""
+    import ctypes
+
+    require_hip(mask, *srcs, op="compact_multi")
+    n = mask.shape[0]
+    srcs = [_f32c(s) for s in srcs]
+    m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
+    outs = [torch.empty_like(s) for s in srcs]
+    k = len(srcs)
+    a_src = (ctypes.c_void_p * k)(*[s.data_ptr() for s in srcs])
+    a_out = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs])
+    a_w = (ctypes.c_int * k)(*[s.numel() // max(n, 1) for s in srcs])
+    cnt = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    ws = workspace(ws_bytes("gs_compact_ws_bytes", n), mask.device, "compact")
+    call("gs_compact_multi", k, a_src, a_w, a_out, ptr(m8), n, ptr(cnt), ptr(ws), ws.numel(), stream())
+    return outs, cnt
+
+
+class _MaskSelectFn(torch.autograd.Function):
+    """x[mask] on (n, C) rows with a scatter adjoint (the reference's boolean-mask indexing)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        ctx.shape = x.shape
+        return compact_rows(x, mask)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out[mask] = g  # adjoint of a gather with unique targets; tiny host-side index op
+        return out, None
+
+
+def mask_select(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _MaskSelectFn.apply(x, mask)
+    return compact_rows(x, mask)
+
+
+# ---------------------------------------------------------------------------------------------- D
+def downsample_frame_raw(depth, gV, gN, rgb, ds: int):
+    """One-frame maps (B,1,H,W,C) -> padded (B,cap,3) x3 + counts (B,) int32 device
+    (reference odometry/icputils.py:651-669)."""
+    require_hip(depth, gV, gN, rgb, op="downsample_frame")
+    depth, gV, gN, rgb = _f32c(depth), _f32c(gV), _f32c(gN), _f32c(rgb)
+    B, _, H, W = depth.shape[:4]
+    cap = ((H + ds - 1) // ds) * ((W + ds - 1) // ds)
+    dev = depth.device
+    mk = lambda src: None if src is None else torch.zeros((B, cap, 3), dtype=torch.float32, device=dev)
+    op, on, oc = mk(gV), mk(gN), mk(rgb)
+    counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    ws = workspace(ws_bytes("gs_downsample_frame_ws_bytes", H, W, ds), dev, "compact")
+    call("gs_downsample_frame", ptr(depth), ptr(gV), ptr(gN), ptr(rgb), B, H, W, ds, cap, ptr(op), ptr(on), ptr(oc),
+         ptr(counts), ptr(ws), ws.numel(), stream())
+    return op, on, oc, counts
+
+
+# ---------------------------------------------------------------------------------------------- P / S
+def project_active_raw(points_padded, counts_dev, poses_b44, K_b44, H: int, W: int, ds: int = 0):
+    """-> (rows buffer (B*Nmax,4) int64, count (1,) int32 device).  Rows beyond count are garbage.
+    reference slam/fusionutils.py:247-282 (+ odometry/icputils.py:596-597 when ds > 0)."""
+    require_hip(points_padded, counts_dev, poses_b44, K_b44, op="project_active")
+    pts, poses, K = _f32c(points_padded), _f32c(poses_b44), _f32c(K_b44)
+    B, Nmax = pts.shape[:2]
+    dev = pts.device
+    rows = torch.empty((B * Nmax, 4), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = workspace(ws_bytes("gs_project_active_ws_bytes", B, Nmax), dev, "project")
+    call("gs_project_active", ptr(pts), ptr(counts_dev), B, Nmax, ptr(poses), ptr(K), H, W, ds, ptr(rows), ptr(cnt),
+         ptr(ws), ws.numel(), stream())
+    return rows, cnt
+
+
+def gather_table_rows_raw(rows, n_rows_dev, max_rows: int, attr_padded, cap: int):
+    """Per-batch gather of attr[b, n] for table rows (sorted by b) -> padded (B,cap,C), counts (B,)."""
+    require_hip(rows, attr_padded, op="gather_table_rows")
+    attr = _f32c(attr_padded)
+    B, Nmax, C = attr.shape
+    dev = attr.device
+    out = torch.zeros((B, max(cap, 1), C), dtype=torch.float32, device=dev)
+    counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    ws = workspace(ws_bytes("gs_gather_table_rows_ws_bytes", B), dev, "gather")
+    call("gs_gather_table_rows", ptr(rows), ptr(n_rows_dev), max_rows, ptr(attr), B, Nmax, C, cap, ptr(out), ptr(counts),
+         ptr(ws), ws.numel(), stream())
+    return out, counts
+
+
+def table_ds_mask(rows: torch.Tensor, ds: int) -> torch.Tensor:
+    require_hip(rows, op="table_ds_mask")
+    rows = rows.contiguous()
+    mask = torch.zeros(rows.shape[0], dtype=torch.uint8, device=rows.device)
+    call("gs_table_ds_mask", ptr(rows), rows.shape[0], ds, ptr(mask), stream())
+    return mask
+
+
+# ---------------------------------------------------------------------------------------------- K / J
+def knn1_raw(src, tgt, ns_dev=None, nt_dev=None) -> torch.Tensor:
+    """src (Ns,3), tgt (Nt,3) -> packed best (Ns,) int64 = dist_bits << 32 | idx."""
+    require_hip(src, tgt, op="knn1")
+    src, tgt = _f32c(src), _f32c(tgt)
+    dev = src.device
+    ns_dev = dev_int(src.shape[0], dev) if ns_dev is None else ns_dev
+    nt_dev = dev_int(tgt.shape[0], dev) if nt_dev is None else nt_dev
+    best = torch.empty(src.shape[0], dtype=torch.int64, device=dev)
+    call("gs_knn1", ptr(src), ptr(ns_dev), src.shape[0], ptr(tgt), ptr(nt_dev), tgt.shape[0], ptr(best), stream())
+    return best
+
+
+def knn1_unpack(best: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    dev = best.device
+    n = best.shape[0]
+    d2 = torch.empty(n, dtype=torch.float32, device=dev)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    call("gs_knn1_unpack", ptr(best), ptr(dev_int(n, dev)), n, ptr(d2), ptr(idx), stream())
+    return d2, idx
+
+
+def knn_points(src: torch.Tensor, tgt: torch.Tensor):
+    """Drop-in for the call `knn_points(src (1,Ns,3), tgt (1,Nt,3))` of reference
+    odometry/icputils.py:200-201: returns (dists (1,Ns,1) squared L2, idx (1,Ns,1) int64)."""
+    d2, idx = knn1_unpack(knn1_raw(src[0].detach(), tgt[0].detach()))
+    return d2.view(1, -1, 1), idx.view(1, -1, 1)
+
+
+def _thresh(dist_thresh) -> float:
+    # negative == None at the C ABI; a user-supplied negative threshold keeps nothing, like 0.0
+    return -1.0 if dist_thresh is None else max(float(dist_thresh), 0.0)
+
+
+def icp_linearize_raw(src, tgt, nrm, best, dist_thresh) -> torch.Tensor:
+    """-> 44 floats: H (36) | g (6) | e | count."""
+    src, tgt, nrm = _f32c(src), _f32c(tgt), _f32c(nrm)
+    dev = src.device
+    out = torch.empty(44, dtype=torch.float32, device=dev)
+    ws = workspace(ws_bytes("gs_icp_linearize_ws_bytes", src.shape[0]), dev, "linearize")
+    call("gs_icp_linearize", ptr(src), ptr(dev_int(src.shape[0], dev)), src.shape[0], ptr(tgt), ptr(nrm), ptr(best),
+         _thresh(dist_thresh), ptr(out), ptr(ws), ws.numel(), stream())
+    return out
+
+
+class _LinearizeFn(torch.autograd.Function):
+    """(src, tgt, nrm | best) -> (H (6,6), g (6,1), e ()) with the scatter adjoint of A.5."""
+
+    @staticmethod
+    def forward(ctx, src, tgt, nrm, best, dist_thresh):
+        out = icp_linearize_raw(src, tgt, nrm, best, dist_thresh)
+        ctx.save_for_backward(src, tgt, nrm, best)
+        ctx.dist_thresh = dist_thresh
+        return out[:36].view(6, 6).clone(), out[36:42].view(6, 1).clone(), out[42].clone()
+
+    @staticmethod
+    def backward(ctx, gH, gg, ge):
+        src, tgt, nrm, best = ctx.saved_tensors
+        src_c, tgt_c, nrm_c = _f32c(src), _f32c(tgt), _f32c(nrm)
+        dev = src.device
+        z = lambda t, n: torch.zeros(n, dtype=torch.float32, device=dev) if t is None else _f32c(t).reshape(-1)
+        gout = torch.cat([z(gH, 36), z(gg, 6), z(ge, 1)])
+        g_src = torch.zeros_like(src_c)
+        g_tgt = torch.zeros_like(tgt_c)
+        g_nrm = torch.zeros_like(nrm_c)
+        call("gs_icp_linearize_backward", ptr(src_c), ptr(dev_int(src_c.shape[0], dev)), src_c.shape[0], ptr(tgt_c),
+             ptr(nrm_c), ptr(best), _thresh(ctx.dist_thresh), ptr(gout), ptr(g_src), ptr(g_tgt), ptr(g_nrm), stream())
+        return g_src, g_tgt, g_nrm, None, None
+
+
+def icp_linearize(src, tgt, nrm, best, dist_thresh):
+    return _LinearizeFn.apply(src, tgt, nrm, best, dist_thresh)
+
+
+def icp_rows_raw(src, tgt, nrm, best, dist_thresh):
+    """-> A (Ns,6), b (Ns,), keep (Ns,) uint8 (rows failing the distance filter are zero)."""
+    src, tgt, nrm = _f32c(src), _f32c(tgt), _f32c(nrm)
+    dev = src.device
+    n = src.shape[0]
+    A = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    b = torch.empty(n, dtype=torch.float32, device=dev)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    call("gs_icp_rows", ptr(src), ptr(dev_int(n, dev)), n, ptr(tgt), ptr(nrm), ptr(best), _thresh(dist_thresh), ptr(A),
+         ptr(b), ptr(keep), stream())
+    return A, b, keep
+
+
+class _TransformFn(torch.autograd.Function):
+    """(pts (N,3), T (4,4)) -> R pts + t (reference geometry/geometryutils.py:780-792)."""
+
+    @staticmethod
+    def forward(ctx, pts, T):
+        p, Tc = _f32c(pts), _f32c(T)
+        out = torch.empty_like(p)
+        call("gs_transform_points", ptr(p), ptr(dev_int(p.shape[0], p.device)), p.shape[0], ptr(Tc), ptr(out), stream())
+        ctx.save_for_backward(p, Tc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, T = ctx.saved_tensors
+        g = _f32c(g)
+        # adjoint w.r.t. the points is the transform by R^T (no translation): same kernel, T' = [R^T 0]
+        Tt = torch.zeros_like(T)
+        Tt[:3, :3] = T[:3, :3].t()
+        Tt[3, 3] = 1.0
+        gp = torch.empty_like(p)
+        call("gs_transform_points", ptr(g), ptr(dev_int(p.shape[0], p.device)), p.shape[0], ptr(Tt.contiguous()), ptr(gp), stream())
+        gT = torch.zeros_like(T)
+        gT[:3, :3] = g.t() @ p  # 3xN @ Nx3: a library GEMM, O(N) once per call
+        gT[:3, 3] = g.sum(0)
+        return gp, gT
+
+
+def transform_points(pts: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+    require_hip(pts, T, op="transform_points")
+    return _TransformFn.apply(pts, T)
+
+
+# ---------------------------------------------------------------------------------------------- X
+def icp_device_loop(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_params=None, want_trace=False,
+                    want_best=False):
+    """Whole (grad)ICP loop on the device, no host sync (reference odometry/icputils.py:310-367,
+    :479-545).  Returns (T (4,4), best_last or None, trace (numiters,48) or None)."""
+    require_hip(src, tgt, nrm, init_T, op="icp")
+    src, tgt, nrm, init_T = _f32c(src.detach()), _f32c(tgt.detach()), _f32c(nrm.detach()), _f32c(init_T.detach())
+    dev = src.device
+    ns, nt = src.shape[0], tgt.shape[0]
+    if ns == 0 or nt == 0:
+        raise ValueError("ICP needs non-empty source and target clouds (got {} and {} points)".format(ns, nt))
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    best = torch.empty(ns, dtype=torch.int64, device=dev) if want_best else None
+    trace = torch.zeros((max(numiters, 1), 48), dtype=torch.float32, device=dev) if want_trace else None
+    ws = workspace(ws_bytes("gs_icp_ws_bytes", ns), dev, "icp")
+    d_ns, d_nt = dev_int(ns, dev), dev_int(nt, dev)
+    if grad_params is None:
+        call("gs_icp_point_to_plane", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),
+             int(numiters), float(damp), _thresh(dist_thresh), ptr(T), ptr(best), ptr(trace), ptr(ws), ws.numel(), stream())
+    else:
+        lmax, Bp, B2, nu = grad_params
+        call("gs_icp_point_to_plane_grad", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),
+             int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp), float(B2), float(nu), ptr(T),
+             ptr(best), ptr(trace), ptr(ws), ws.numel(), stream())
+    return T, best, trace
+
+
+# ---------------------------------------------------------------------------------------------- C / U / F / A
+def fusion_similar_raw(rows, n_rows_dev, max_rows, gV, gN, map_points, map_normals, dist_th, dot_th):
+    """-> keep (max_rows,) uint8, max_dot (1,) float32 device."""
+    gV, gN, mp, mn = _f32c(gV), _f32c(gN), _f32c(map_points), _f32c(map_normals)
+    H, W = gV.shape[2:4]
+    dev = gV.device
+    keep = torch.zeros(max(max_rows, 1), dtype=torch.uint8, device=dev)
+    max_dot = torch.zeros(1, dtype=torch.float32, device=dev)
+    call("gs_fusion_similar", ptr(rows), ptr(n_rows_dev), max_rows, ptr(gV), ptr(gN), H, W, ptr(mp), ptr(mn),
+         mp.shape[1], float(dist_th), float(dot_th), ptr(keep), ptr(max_dot), stream())
+    return keep, max_dot
+
+
+def fusion_unique_raw(rows, keep, n_rows_dev, max_rows, gV, map_points, map_ccounts):
+    """-> (rows buffer (B*H*W,4) int64, count (1,) int32 device)."""
+    gV, mp, cc = _f32c(gV), _f32c(map_points), _f32c(map_ccounts)
+    B, _, H, W = gV.shape[:4]
+    dev = gV.device
+    out = torch.empty((B * H * W, 4), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = workspace(ws_bytes("gs_fusion_unique_ws_bytes", B, H, W), dev, "unique")
+    call("gs_fusion_unique", ptr(rows), ptr(keep), ptr(n_rows_dev), max_rows, ptr(gV), B, H, W, ptr(mp), ptr(cc),
+         mp.shape[1], ptr(out), ptr(cnt), ptr(ws), ws.numel(), stream())
+    return out, cnt
+
+
+def fusion_merge_raw(rows, n_rows_dev, max_rows, gV, gN, rgb, alpha, counts_dev, mp, mn, mc, cc):
+    """-> new (points, normals, colors, ccounts), each a fresh (B,Nmax,C) tensor."""
+    B, _, H, W = gV.shape[:4]
+    Nmax = mp.shape[1]
+    dev = gV.device
+    op, on, oc, occ = (torch.empty_like(x) for x in (mp, mn, mc, cc))
+    ws = workspace(ws_bytes("gs_fusion_merge_ws_bytes", B, Nmax), dev, "merge")
+    call("gs_fusion_merge", ptr(rows), ptr(n_rows_dev), max_rows, ptr(gV), ptr(gN), ptr(rgb), ptr(alpha), B, H, W, Nmax,
+         ptr(counts_dev), ptr(mp), ptr(mn), ptr(mc), ptr(cc), ptr(op), ptr(on), ptr(oc), ptr(occ), ptr(ws), ws.numel(),
+         stream())
+    return op, on, oc, occ
+
+
+class _MergeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, counts_dev, gV, gN, rgb, alpha, mp, mn, mc, cc):
+        gV, gN, rgb, alpha, mp, mn, mc, cc = (_f32c(x) for x in (gV, gN, rgb, alpha, mp, mn, mc, cc))
+        n_dev = dev_int(rows.shape[0], rows.device)
+        outs = fusion_merge_raw(rows, n_dev, rows.shape[0], gV, gN, rgb, alpha, counts_dev, mp, mn, mc, cc)
+        ctx.save_for_backward(rows, counts_dev, gV, gN, rgb, alpha, mp, mn, mc, cc)
+        return outs
+
+    @staticmethod
+    def backward(ctx, gop, gon, goc, gocc):
+        rows, counts_dev, gV, gN, rgb, alpha, mp, mn, mc, cc = ctx.saved_tensors
+        B, _, H, W = gV.shape[:4]
+        Nmax = mp.shape[1]
+        dev = gV.device
+        gop, gon, goc, gocc = (None if g is None else _f32c(g) for g in (gop, gon, goc, gocc))
+        gip, ginn, gic, gicc = (torch.empty_like(x) for x in (mp, mn, mc, cc))
+        ggv, ggn, grgb, galpha = (torch.zeros_like(x) for x in (gV, gN, rgb, alpha))
+        ws = workspace(ws_bytes("gs_fusion_merge_ws_bytes", B, Nmax), dev, "merge")
+        call("gs_fusion_merge_backward", ptr(rows), ptr(dev_int(rows.shape[0], dev)), rows.shape[0], ptr(gV), ptr(gN),
+             ptr(rgb), ptr(alpha), B, H, W, Nmax, ptr(counts_dev), ptr(mp), ptr(mn), ptr(mc), ptr(cc), ptr(gop), ptr(gon),
+             ptr(goc), ptr(gocc), ptr(gip), ptr(ginn), ptr(gic), ptr(gicc), ptr(ggv), ptr(ggn), ptr(grgb), ptr(galpha),
+             ptr(ws), ws.numel(), stream())
+        return None, None, ggv, ggn, grgb, galpha, gip, ginn, gic, gicc
+
+
+def fusion_merge(rows, counts_dev, gV, gN, rgb, alpha, mp, mn, mc, cc):
+    """Autograd-aware merge of the unique rows into the padded map arrays."""
+    return _MergeFn.apply(rows, counts_dev, gV, gN, rgb, alpha, mp, mn, mc, cc)
+
+
+def fusion_new_mask_raw(depth, rows, n_rows_dev, max_rows):
+    """depth (B,1,H,W,1) -> mask (B,H,W) uint8: valid depth and not matched."""
+    depth = _f32c(depth)
+    B, _, H, W = depth.shape[:4]
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=depth.device)
+    call("gs_fusion_new_mask", ptr(depth), ptr(rows), ptr(n_rows_dev), max_rows, B, H, W, ptr(mask), stream())
+    return mask

@@ -1,0 +1,241 @@
+/* gradslam_hip.h -- C ABI of libgradslam_hip.so: the MI355X (gfx950) hot path of gradslam's
+ * point-to-plane ICP odometry and PointFusion map update.
+ *
+ * The reference (EdwardjkFeng/gradslam) has no FFI for this path: it is pure Python on torch ops
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces a *chain of torch ops* in the
+ * reference, cited as file:line relative to the reference root; INTEGRATION.md shows the ctypes
+ * stub a gradslam maintainer would add at that call site.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless its name starts with h_;
+ *  - float tensors are fp32, row-major, densely packed; index tables are int64 rows [b,n,h,w]
+ *    exactly as the reference's pc2im_bnhw; counts are int32;
+ *  - images are channels-last: depth (B,L,H,W), maps (B,L,H,W,3); clouds are zero-padded
+ *    (B,Nmax,C) with per-batch counts[B] (reference structures/pointclouds.py "padded" form);
+ *  - 4x4 matrices are 16 contiguous floats, row-major;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *    the host, nothing allocates (capturable in a hipGraph).  Scratch comes from the caller
+ *    (`ws`, sized by the matching *_ws_bytes function);
+ *  - return value: 0 on success, GS_ERR_* (<0) for an invalid argument, a positive hipError_t if
+ *    a launch failed.  gs_last_error() describes the last failure of the calling thread.
+ */
+#ifndef GRADSLAM_HIP_H
+#define GRADSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+#define GS_OK 0
+#define GS_ERR_INVALID_ARG (-1)
+#define GS_ERR_WORKSPACE_TOO_SMALL (-2)
+#define GS_ERR_UNSUPPORTED (-3)
+
+typedef void *gs_stream_t;
+
+int gs_abi_version(void);
+const char *gs_last_error(void);
+
+/* ---------------------------------------------------------------- V: depth -> vertex/normal maps
+ * Replaces RGBDImages._compute_vertex_map / _compute_normal_map / _compute_global_vertex_map /
+ * _compute_global_normal_map (structures/rgbdimages.py:643-762) and inverse_intrinsics
+ * (geometry/projutils.py:437-450), fused into one pass.  Any output pointer may be NULL.
+ * poses == NULL reproduces the "poses is None -> clone" branch (global = local). */
+int gs_vertex_normal_maps(const float *depth, const float *intrinsics /* B x 16 */,
+                          const float *poses /* B*L x 16 or NULL */, int B, int L, int H, int W,
+                          float *vertex, float *normal, float *gvertex, float *gnormal,
+                          gs_stream_t stream);
+
+/* Adjoint of the above: given d(loss)/d(map) for any subset of the four maps (NULL = zero),
+ * accumulates d/d(depth) (B,L,H,W), d/d(intrinsics) (B x 16: fx,fy,cx,cy slots) and
+ * d/d(poses) (B*L x 16: R and t slots).  Outputs must be zero-initialised by the caller. */
+size_t gs_vertex_normal_maps_backward_ws_bytes(int B, int L, int H, int W);
+int gs_vertex_normal_maps_backward(const float *depth, const float *intrinsics, const float *poses,
+                                   int B, int L, int H, int W, const float *g_vertex,
+                                   const float *g_normal, const float *g_gvertex,
+                                   const float *g_gnormal, float *g_depth, float *g_intrinsics,
+                                   float *g_poses, void *ws, size_t ws_bytes, gs_stream_t stream);
+
+/* get_alpha (slam/fusionutils.py:69-73) on an (n,3) block: clamp(exp(-|p|^2/(2 sigma^2)), eps, 1.01) */
+int gs_get_alpha(const float *points, int64_t n, float sigma, float eps, float *alpha,
+                 gs_stream_t stream);
+int gs_get_alpha_backward(const float *points, int64_t n, float sigma, float eps,
+                          const float *g_alpha, float *g_points, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- generic stable compaction
+ * out = rows of `src` (n_rows x row_floats fp32) whose mask byte is non-zero, order preserved;
+ * *out_count = number kept.  Replaces the boolean-mask indexing x[mask] the reference uses at
+ * odometry/icputils.py:654-668, slam/fusionutils.py:282,401,710-713, structures/utils.py:47-50. */
+size_t gs_compact_ws_bytes(int64_t n_rows);
+int gs_compact_rows(const float *src, const uint8_t *mask, int64_t n_rows, int row_floats,
+                    float *out, int32_t *out_count, void *ws, size_t ws_bytes, gs_stream_t stream);
+
+/* Same, for up to 4 row arrays sharing one mask and one scan (h_src / h_row_floats / h_out are HOST
+ * arrays of n_arrays device pointers / widths): the append of fuse_with_map compacts vertex, normal,
+ * colour and alpha rows of the new pixels in one go (slam/fusionutils.py:710-713). */
+int gs_compact_multi(int n_arrays, const float *const *h_src, const int *h_row_floats,
+                     float *const *h_out, const uint8_t *mask, int64_t n_rows, int32_t *out_count,
+                     void *ws, size_t ws_bytes, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- D: live frame -> ICP source cloud
+ * downsample_rgbdimages (odometry/icputils.py:651-669): [::ds, ::ds] sub-grid of the global
+ * vertex / normal maps and the rgb image of ONE frame per batch element (L == 1), valid-depth
+ * pixels only, row-major order.  Outputs are padded (B, cap, 3) with cap >= ceil(H/ds)*ceil(W/ds);
+ * counts[b] receives the number of rows written for batch b.  Any of the three outputs may be NULL. */
+size_t gs_downsample_frame_ws_bytes(int H, int W, int ds);
+int gs_downsample_frame(const float *depth, const float *gvertex, const float *gnormal,
+                        const float *rgb, int B, int H, int W, int ds, int cap, float *out_points,
+                        float *out_normals, float *out_colors, int32_t *counts, void *ws,
+                        size_t ws_bytes, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- P: active map points
+ * find_active_map_points (slam/fusionutils.py:247-282): inverse pose, transform every map point,
+ * pinhole projection, in-frame test, round-half-to-even, rows [b,n,h,w] kept in (b,n) order.
+ * points: padded (B,Nmax,3); counts[B]; poses/intrinsics: B x 16.  out_rows capacity: B*Nmax rows.
+ * ds > 0 additionally keeps only rows with h%ds==0 && w%ds==0 (downsample_pointclouds' filter,
+ * odometry/icputils.py:596-597); ds <= 0 keeps all. */
+size_t gs_project_active_ws_bytes(int B, int Nmax);
+int gs_project_active(const float *points, const int32_t *counts, int B, int Nmax,
+                      const float *poses, const float *intrinsics, int H, int W, int ds,
+                      int64_t *out_rows, int32_t *out_count, void *ws, size_t ws_bytes,
+                      gs_stream_t stream);
+
+/* S: downsample_pointclouds' gather (odometry/icputils.py:600-619): for batch element b, gather
+ * attribute rows `attr[b, n]` for every table row with row.b == b, order preserved, into a padded
+ * (B, cap, C) output; counts[b] = rows written.  n_rows is read from d_n_rows (device). */
+size_t gs_gather_table_rows_ws_bytes(int B);
+int gs_gather_table_rows(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
+                         const float *attr, int B, int Nmax, int C, int cap, float *out,
+                         int32_t *counts, void *ws, size_t ws_bytes, gs_stream_t stream);
+
+/* keep mask of downsample_pointclouds' row filter for an arbitrary table
+ * (odometry/icputils.py:596-597): mask[i] = rows[i].h % ds == 0 && rows[i].w % ds == 0 */
+int gs_table_ds_mask(const int64_t *rows, int64_t n_rows, int ds, uint8_t *mask, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- K: exact 1-nearest neighbour
+ * Replaces chamferdist.knn_points(src, tgt) with K=1 (call site odometry/icputils.py:200-201):
+ * for each source point the squared L2 distance ((dx^2+dy^2)+dz^2, fp32, no FMA) to, and index of,
+ * the nearest target point; the lowest index wins ties.  ns / nt are read from device memory
+ * (d_ns, d_nt) so the call needs no host round trip; max_ns / max_nt bound the launch.
+ * best: packed (dist_bits << 32 | idx) per source point, the form the J kernels consume. */
+int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+            const int32_t *d_nt, int max_nt, uint64_t *best, gs_stream_t stream);
+/* unpack to the reference's output types: dist2 fp32 (ns), idx int64 (ns) */
+int gs_knn1_unpack(const uint64_t *best, const int32_t *d_ns, int max_ns, float *dist2,
+                   int64_t *idx, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- J: linearise + reduce
+ * gauss_newton_solve's algebra (odometry/icputils.py:203-232) fused with the normal-equation
+ * products of solve_linear_system (:85-87) and the error dot product (:340): from src, tgt,
+ * tgt normals and the packed nearest neighbours, accumulate
+ *    H = sum a a^T (6x6), g = sum a b (6), e = sum b^2, cnt = #rows,
+ * a = [n ; s x n], b = n.(d - s), over rows with dist2 < dist_thresh (dist_thresh < 0: all rows;
+ * NB the reference compares the threshold with the SQUARED distance).
+ * out: 44 floats = H (36, row-major) | g (6) | e | cnt (as float).  Deterministic (fixed-order
+ * two-level reduction, no float atomics). */
+size_t gs_icp_linearize_ws_bytes(int max_ns);
+int gs_icp_linearize(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                     const float *tgt_normals, const uint64_t *best, float dist_thresh,
+                     float *out44, void *ws, size_t ws_bytes, gs_stream_t stream);
+
+/* Rows form of the same algebra for API parity with gauss_newton_solve: A (ns,6), b (ns), and a
+ * keep mask (ns) u8; callers compact with gs_compact_rows. */
+int gs_icp_rows(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                const float *tgt_normals, const uint64_t *best, float dist_thresh, float *A,
+                float *b, uint8_t *keep, gs_stream_t stream);
+
+/* Adjoint of gs_icp_linearize: given d/dH (36), d/dg (6), d/de (1) in g_out43, accumulate
+ * d/dsrc (ns,3) (plain stores) and d/dtgt, d/dnormals (nt,3) (atomic scatter-add; zero-init). */
+int gs_icp_linearize_backward(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                              const float *tgt_normals, const uint64_t *best, float dist_thresh,
+                              const float *g_out43, float *g_src, float *g_tgt, float *g_normals,
+                              gs_stream_t stream);
+
+/* transform_pointcloud (geometry/geometryutils.py:780-792): out = R p + t, T is a DEVICE 4x4. */
+int gs_transform_points(const float *pts, const int32_t *d_n, int max_n, const float *T,
+                        float *out, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- X: whole ICP loops on device
+ * point_to_plane_ICP (odometry/icputils.py:310-367): LM loop with the accept/reject decision kept
+ * on the device.  src (ns,3), tgt/normals (nt,3), init_T (device 4x4).  Outputs: T (device 4x4),
+ * optional best_last (packed NN of the last iteration's first solve) and optional trace
+ * (numiters x 48 floats: H36|g6|err|new_err|damp|accept|cnt|pad).  dist_thresh < 0 == None. */
+size_t gs_icp_ws_bytes(int max_ns);
+int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                          const float *tgt_normals, const int32_t *d_nt, int max_nt,
+                          const float *init_T, int numiters, float damp, float dist_thresh,
+                          float *out_T, uint64_t *best_last, float *trace, void *ws,
+                          size_t ws_bytes, gs_stream_t stream);
+
+/* point_to_plane_gradICP (odometry/icputils.py:479-545): the smooth gradLM variant. */
+int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                               const float *tgt_normals, const int32_t *d_nt, int max_nt,
+                               const float *init_T, int numiters, float damp, float dist_thresh,
+                               float lambda_max, float B, float B2, float nu, float *out_T,
+                               uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
+                               gs_stream_t stream);
+
+/* ---------------------------------------------------------------- C+U: fusion correspondences
+ * find_similar_map_points (slam/fusionutils.py:381-401): keep[i] = |Vg(b,h,w) - p(b,n)| < dist_th
+ * (Euclidean) && Ng(b,h,w).nrm(b,n) > dot_th for every table row; max_dot (device float, may be
+ * NULL) receives the maximum dot product (the reference warns when it exceeds 1.001). */
+int gs_fusion_similar(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
+                      const float *gvertex, const float *gnormal, int H, int W,
+                      const float *map_points, const float *map_normals, int Nmax, float dist_th,
+                      float dot_th, uint8_t *keep, float *max_dot, gs_stream_t stream);
+
+/* find_best_unique_correspondences (slam/fusionutils.py:489-546): per (b,h,w) keep the row
+ * minimising (1/(ccount+1e-20), squared ray distance, n) compared as fp32; output rows [b,n,h,w]
+ * sorted by (b,h,w).  `keep` (may be NULL = all) pre-filters rows, which fuses the compaction of
+ * find_similar_map_points.  Replaces the reference's torch.unique(dim=0) row sort. */
+size_t gs_fusion_unique_ws_bytes(int B, int H, int W);
+int gs_fusion_unique(const int64_t *rows, const uint8_t *keep, const int32_t *d_n_rows,
+                     int64_t max_rows, const float *gvertex, int B, int H, int W,
+                     const float *map_points, const float *map_ccounts, int Nmax,
+                     int64_t *out_rows, int32_t *out_count, void *ws, size_t ws_bytes,
+                     gs_stream_t stream);
+
+/* ---------------------------------------------------------------- F: merge matched points
+ * fuse_with_map's weighted running average (slam/fusionutils.py:654-699).  EVERY map point goes
+ * through the reference's formula  c' = c + alpha, x' = (c x + alpha x_f) * (1 / (c'==0 ? 1 : c'))
+ * for points, normals and colours, with alpha = x_f = 0 for points that are not in `rows` (the
+ * reference evaluates it on the whole padded tensors, which perturbs unmatched points by rounding;
+ * that is part of its observable result).  Reads the in_* arrays (B,Nmax,C), writes the out_*
+ * arrays (may alias in_* for an in-place update).  alpha (B,H,W) = get_alpha(local vertex map). */
+size_t gs_fusion_merge_ws_bytes(int B, int Nmax);
+int gs_fusion_merge(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
+                    const float *gvertex, const float *gnormal, const float *rgb,
+                    const float *alpha, int B, int H, int W, int Nmax, const int32_t *counts,
+                    const float *in_points, const float *in_normals, const float *in_colors,
+                    const float *in_ccounts, float *out_points, float *out_normals,
+                    float *out_colors, float *out_ccounts, void *ws, size_t ws_bytes,
+                    gs_stream_t stream);
+/* Adjoint.  g_in_* (B,Nmax,C) are overwritten; g_gvertex/g_gnormal/g_rgb (B,H,W,3) and g_alpha
+ * (B,H,W) receive plain stores at matched pixels only (zero-init by the caller).  Any g_* may be
+ * NULL. */
+int gs_fusion_merge_backward(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
+                             const float *gvertex, const float *gnormal, const float *rgb,
+                             const float *alpha, int B, int H, int W, int Nmax,
+                             const int32_t *counts, const float *in_points,
+                             const float *in_normals, const float *in_colors,
+                             const float *in_ccounts, const float *g_out_points,
+                             const float *g_out_normals, const float *g_out_colors,
+                             const float *g_out_ccounts, float *g_in_points, float *g_in_normals,
+                             float *g_in_colors, float *g_in_ccounts, float *g_gvertex,
+                             float *g_gnormal, float *g_rgb, float *g_alpha, void *ws,
+                             size_t ws_bytes, gs_stream_t stream);
+
+/* ---------------------------------------------------------------- A: new-point mask
+ * fuse_with_map's append mask (slam/fusionutils.py:702-707): mask = valid_depth && pixel not in
+ * `rows` (B,H,W) u8.  Callers then compact gvertex/gnormal/rgb/alpha with gs_compact_rows per b. */
+int gs_fusion_new_mask(const float *depth, const int64_t *rows, const int32_t *d_n_rows,
+                       int64_t max_rows, int B, int H, int W, uint8_t *mask, gs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRADSLAM_HIP_H */
