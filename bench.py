@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- RGB-D frames/sec of the per-frame point-to-plane ICP hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "c2"): synthetic TUM-shape 640x480 RGB-D, batch 1 per GPU,
+dsratio 4, 10 ICP iterations.  One STEP = localising one live frame against the map, inputs already
+resident in HBM: depth -> vertex/normal maps (local+global), ds-grid source cloud, active-map-point
+projection of the ~300 k-point map + ds-grid target cloud, 10-iteration LM point-to-plane ICP
+(exact 1-NN association, 6x6 Gauss-Newton reduce/solve, SE(3) exp, accept/reject on device), pose
+composition -- i.e. ICPSLAM._localize of the reference (slam/icpslam.py:238-247), nothing skipped.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel of the timed region (the
+exact nearest-neighbour association kernel, FP32-VALU bound: priced against the 157.3 TFLOP/s FP32
+peak, which is the same number for the vector and the f32 matrix pipes); `roofline_hbm` describes the
+linearise+reduce kernel (J) at a size that streams from HBM (2^24 points), where an HBM fraction is
+physically meaningful.  Kernel durations come from HIP events recorded on
+the launch stream inside the C library (gs_profile_*).  `cpu_baseline` times the CPU oracle on a
+bounded sample of the same workload on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, DS, ITERS = 480, 640, 4, 10
+N_LIVE = 4  # distinct live frames cycled through (fresh RGBDImages each step: nothing is cached)
+
+
+def build_workload(gs, dev, seed):
+    from gradslam_amd.synthetic import make_sequence
+
+    c, d, K, P = make_sequence(1, 1 + N_LIVE, H, W, seed=seed)
+    c, d, K, P = c.to(dev), d.to(dev), K.to(dev), P.to(dev)
+    slam = gs.slam.PointFusion(odom="icp", dsratio=DS, numiters=ITERS, device=dev)
+    frames = gs.RGBDImages(c, d, K, P)
+    with torch.no_grad():
+        f0 = frames[:, 0]
+        world_map, _ = slam.step(gs.Pointclouds(device=dev), f0, None)  # map after frame 0
+    lives = [(c[:, s:s + 1].contiguous(), d[:, s:s + 1].contiguous()) for s in range(1, 1 + N_LIVE)]
+    return slam, world_map, f0, lives, K, (c, d, K, P)
+
+
+def one_step(gs, slam, world_map, prev, live_cd, K):
+    live = gs.RGBDImages(live_cd[0], live_cd[1], K)  # fresh object: maps are recomputed every step
+    return slam._localize(world_map, live, prev)
+
+
+def prof_read(nv, tag):
+    n, ms = ctypes.c_long(0), ctypes.c_double(0.0)
+    nv.lib().gs_profile_read(tag, ctypes.byref(n), ctypes.byref(ms))
+    return n.value, ms.value
+
+
+def hbm_roofline_linearize(gs, dev, n_pts=1 << 24, reps=20):
+    """J (linearise + 6x6 reduce) on 2^24 points with image-order-coherent associations: 40
+    algorithmic bytes per source point (src 12 + idx 4 + gathered tgt 12 + gathered normal 12)."""
+    from gradslam_amd import ops
+    from gradslam_amd._native import call, ptr, stream, workspace, ws_bytes
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    src = torch.rand((n_pts, 3), device=dev, generator=g)
+    tgt = src + 0.01
+    nrm = torch.nn.functional.normalize(torch.rand((n_pts, 3), device=dev, generator=g), dim=-1)
+    idx = torch.arange(n_pts, device=dev, dtype=torch.int64)
+    jitter = torch.randint(-8, 9, (n_pts,), device=dev, generator=g)
+    idx = (idx + jitter).clamp_(0, n_pts - 1)
+    d2 = torch.full((n_pts,), 1e-4, device=dev).view(torch.int32).to(torch.int64)
+    best = (d2 << 32) | idx
+    out = torch.empty(44, device=dev)
+    ws = workspace(ws_bytes("gs_icp_linearize_ws_bytes", n_pts), dev, "linearize")
+    d_n = ops.dev_int(n_pts, dev)
+    run = lambda: call("gs_icp_linearize", ptr(src), ptr(d_n), n_pts, ptr(tgt), ptr(nrm), ptr(best), -1.0, ptr(out), ptr(ws),
+                       ws.numel(), stream())
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:  # torch's current stream IS the stream the kernel is launched on (stream())
+        a.record()
+        run()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    avg = sum(ms) / len(ms)
+    alg = 40.0 * n_pts
+    ach = alg / (avg * 1e-3) / 1e9
+    return {"kernel": "linearize_k+finalize44_k (gs_icp_linearize)", "bound": "hbm", "achieved": round(ach, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None, "n_points": n_pts,
+            "bytes_per_point": 40, "avg_launch_ms": round(avg, 4),
+            "note": "peak = 8.0 TB/s HBM3E spec (6.29 TB/s is the measured float4-copy ceiling)"}
+
+
+def cpu_baseline(raw, n_frames=24):
+    """The CPU oracle (kind 'port') on the same workload: localise live frames 1..n against the map."""
+    from oracle import fusion as ofu
+    from oracle import knn as oknn
+    from oracle import slam as oslam
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    oknn.set_threads(cores)
+    c, d, K, P = (x.cpu() for x in raw)
+    f0 = ofu.make_frame(c[:, :1], d[:, :1], K, P[:, :1])
+    from oracle.cloud import Cloud
+
+    cloud = ofu.update_map_fusion(Cloud(), f0, 0.05, math.cos(math.radians(20)), 0.6)
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        s = 1 + i % N_LIVE
+        live = ofu.make_frame(c[:, s:s + 1], d[:, s:s + 1], K, f0["pose"])
+        oslam.localize(cloud, live, f0, "icp", DS, numiters=ITERS, damp=1e-8, dist_thresh=None)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "{} frames of the same 640x480/ds4/10-iter localisation step, CPU oracle "
+                      "(torch CPU ops + OpenMP C nearest-neighbour), {:.1f} s".format(n_frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import gradslam_amd as gs
+    from gradslam_amd import _native as nv
+    from gradslam_amd import parallel
+
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nv.lib()
+
+    slam, world_map, prev, lives, K, raw = build_workload(gs, dev, seed=rank)
+    n_map = int(world_map.num_points_per_pointcloud.item())
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    poses = []
+    with torch.no_grad():
+        for i in range(args.warmup):
+            one_step(gs, slam, world_map, prev, lives[i % N_LIVE], K)
+        nv.lib().gs_profile_enable(1)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            poses.append(one_step(gs, slam, world_map, prev, lives[i % N_LIVE], K))
+        local_poses = torch.cat(poses, 1)                      # (1, K, 4, 4)
+        all_poses = parallel.gather_poses(local_poses, world)  # final RCCL gather of the poses
+        barrier()
+        dt = time.perf_counter() - t0
+    nv.lib().gs_profile_enable(0) if False else None
+    n_knn, ms_knn = prof_read(nv, 0)
+    n_lin, ms_lin = prof_read(nv, 1)
+    nv.lib().gs_profile_enable(0)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        # sanity: the recovered motion is the synthetic trajectory's (guards against a fast wrong answer)
+        ref = raw[3][0, 1:1 + N_LIVE].cpu()
+        got = all_poses[0, :min(args.steps, N_LIVE)].cpu()
+        pose_err = float((got - ref[: got.shape[0]]).abs().max()) if got.numel() else 0.0
+        ns = nt = (H // DS) * (W // DS)
+        avg_knn_ms = ms_knn / max(n_knn, 1)
+        flops = 8.0 * ns * nt
+        ach = flops / (avg_knn_ms * 1e-3) / 1e12 if n_knn else 0.0
+        line = {
+            "metric": "RGB-D frames/sec (640x480, 10 ICP iters)",
+            "value": round(world * args.steps / dt, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "c2: ICP odometry localisation step, 640x480 TUM-shape synthetic RGB-D, batch 1 per GPU, "
+                                   "dsratio 4 (~19k x ~19k points), 10 LM iterations, map {} points".format(n_map),
+                       "parallelism": "one sequence per GPU, final RCCL all_gather of poses", "pose_max_abs_err": pose_err},
+            "roofline": {"kernel": "knn1_sel_k (exact 1-NN association)", "bound": "mfma", "achieved": round(ach, 2),
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+                         "launches": n_knn, "avg_launch_ms": round(avg_knn_ms, 5), "flops_per_launch": flops,
+                         "note": "FP32-VALU-bound kernel (no dense contraction, MFMA unused); 157.3 TFLOP/s is the FP32 "
+                                 "peak of both the vector and the f32 matrix pipe; 8 flop per src x tgt pair, ~19.2k x ~19.2k "
+                                 "pairs upper bound per launch"},
+            "roofline_linearize_c2": {"kernel": "linearize_sel_k", "launches": n_lin,
+                                      "avg_launch_ms": round(ms_lin / max(n_lin, 1), 5),
+                                      "note": "0.77 MB per launch: L2-resident, launch-bound -- not an HBM measurement"},
+        }
+        try:
+            line["roofline_hbm"] = hbm_roofline_linearize(gs, dev)
+        except Exception as e:  # pragma: no cover
+            line["roofline_hbm"] = {"error": str(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(raw)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

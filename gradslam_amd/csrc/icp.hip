@@ -10,6 +10,8 @@
 // exactly the reference's strict-< scan order).
 // J is a gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; it
 // reduces with wave butterflies and a fixed-order two-level tree (deterministic, no float atomics).
+#include <vector>
+
 #include "gs_common.hpp"
 
 namespace gs {
@@ -569,6 +571,30 @@ static inline int lin_blocks(int max_ns) {
     return nb;
 }
 
+// ------------------------------------------------------------------ optional per-kernel timing
+// bench.py asks for the average duration of the two hot kernels of the loop, measured with HIP events
+// on the stream they are launched on.  Off by default (no events, no overhead).
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev[2][2];  // [tag][start|stop]
+    size_t used[2] = {0, 0};
+    double total_ms[2] = {0.0, 0.0};
+    long count[2] = {0, 0};
+};
+static Prof g_prof;
+static inline void prof_mark(int tag, int which, hipStream_t st) {
+    if (!g_prof.on) return;
+    auto &v = g_prof.ev[tag][which];
+    const size_t i = g_prof.used[tag];
+    if (i >= v.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        v.push_back(e);
+    }
+    (void)hipEventRecord(v[i], st);
+    if (which == 1) g_prof.used[tag] = i + 1;
+}
+
 struct IcpWs {
     IcpState *S;
     float *bufA, *bufB;
@@ -617,10 +643,14 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         return GS_OK;
     }
     auto assoc = [&](int first, int gm) {
+        prof_mark(0, 0, st);
         hipLaunchKernelGGL(knn1_sel_k, kgrid, dim3(KNN_T), 0, st, w.S, first, src, w.bufA, w.bufB, d_ns, tgt, d_nt, nsplit,
                            w.bestA, w.bestB, gm);
+        prof_mark(0, 1, st);
+        prof_mark(1, 0, st);
         hipLaunchKernelGGL(linearize_sel_k, dim3(lb), dim3(LIN_T), 0, st, w.S, first, w.bufA, w.bufB, d_ns, tgt, nrm,
                            w.bestA, w.bestB, thresh, gm, w.partials);
+        prof_mark(1, 1, st);
     };
     auto step = [&](int mode, int last) {
         hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(64), 0, st, w.S, w.partials, lb, mode, last, gp, trace, w.bestA,
@@ -661,6 +691,30 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
 using namespace gs;
 
 extern "C" {
+
+void gs_profile_enable(int on) {
+    g_prof.on = on != 0;
+    for (int t = 0; t < 2; ++t) { g_prof.used[t] = 0; g_prof.total_ms[t] = 0.0; g_prof.count[t] = 0; }
+}
+
+// Fold the events recorded so far into the totals (the caller must have synchronised the stream)
+// and return, for tag 0 (association kernel) / 1 (linearise kernel), launches and total milliseconds.
+int gs_profile_read(int tag, long *launches, double *total_ms) {
+    GS_REQUIRE(tag == 0 || tag == 1, "gs_profile_read: tag must be 0 or 1");
+    for (int t = 0; t < 2; ++t) {
+        for (size_t i = 0; i < g_prof.used[t]; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, g_prof.ev[t][0][i], g_prof.ev[t][1][i]) == hipSuccess) {
+                g_prof.total_ms[t] += ms;
+                g_prof.count[t] += 1;
+            }
+        }
+        g_prof.used[t] = 0;
+    }
+    if (launches) *launches = g_prof.count[tag];
+    if (total_ms) *total_ms = g_prof.total_ms[tag];
+    return GS_OK;
+}
 
 int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const int32_t *d_nt, int max_nt,
             uint64_t *best, gs_stream_t stream) {

@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void vn_bwd_pass1_k(const float *__restrict__ 
         const f3 b0 = vertex_of(k, hl, w, dimg[(int64_t)hl * W + w]);
         const f3 b1 = vertex_of(k, hl + 1, w, dimg[(int64_t)(hl + 1) * W + w]);
         const f3 dh{a1.x - a0.x, a1.y - a0.y, a1.z - a0.z}, dv{b1.x - b0.x, b1.y - b0.y, b1.z - b0.z};
-        f3 c{dh.y * dv.z - dh.z * dv.y, dh.z * dv.x - dh.x * dv.z, dh.x * dv.y - dh.y * dv.x};
-        const float s = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
+        // same contractions as the forward pass, so degenerate pixels (both neighbours invalid ->
+        // dh == dv, cross = fma residue) take the same branch and see the same tiny norm
+        f3 c{__fmaf_rn(dh.y, dv.z, -(dh.z * dv.y)), __fmaf_rn(dh.z, dv.x, -(dh.x * dv.z)),
+             __fmaf_rn(dh.x, dv.y, -(dh.y * dv.x))};
+        const float s = sqrtf(__fmaf_rn(c.z, c.z, __fmaf_rn(c.y, c.y, c.x * c.x)));
         const float sdiv = (s == 0.0f) ? 1.0f : s;
         const f3 nh{c.x / sdiv, c.y / sdiv, c.z / sdiv};
         // total adjoint of the masked local normal N = m * nh

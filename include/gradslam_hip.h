@@ -179,6 +179,13 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
                                uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
                                gs_stream_t stream);
 
+/* Optional timing of the two hot kernels of the loops above with HIP events recorded on the launch
+ * stream (used by bench.py for the roofline line; off by default).  gs_profile_read folds the events
+ * recorded so far (caller synchronises first) and returns launches / total ms for tag 0 = association
+ * kernel, 1 = linearise kernel. */
+void gs_profile_enable(int on);
+int gs_profile_read(int tag, long *launches, double *total_ms);
+
 /* ---------------------------------------------------------------- C+U: fusion correspondences
  * find_similar_map_points (slam/fusionutils.py:381-401): keep[i] = |Vg(b,h,w) - p(b,n)| < dist_th
  * (Euclidean) && Ng(b,h,w).nrm(b,n) > dot_th for every table row; max_dot (device float, may be

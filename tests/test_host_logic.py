@@ -1,0 +1,291 @@
+"""CPU (no GPU) tests: the C ABI exports what include/gradslam_hip.h declares, the product refuses to
+compute without a HIP device (no fallback), and the host-side mirror of the reference interface keeps
+its container semantics and error contracts (messages matched like the reference's own tests do)."""
+import os
+import re
+
+import pytest
+import torch
+
+import gradslam_amd as gs
+from gradslam_amd import _native
+from gradslam_amd.odometry import icputils
+from gradslam_amd.slam import fusionutils
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+def _declared():
+    text = open(os.path.join(REPO, "include", "gradslam_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.lib()  # loads without a GPU; no compute calls here
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_native.SIGNATURES) == names
+    assert lib.gs_abi_version() == 1
+
+
+def test_abi_is_plain_c():
+    text = open(os.path.join(REPO, "include", "gradslam_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert 'extern "C"' in code
+    assert "at::" not in code and "Tensor" not in code and "std::" not in code
+
+
+def test_product_refuses_cpu_tensors():
+    r = gs.RGBDImages(torch.rand(1, 1, 8, 8, 3), torch.rand(1, 1, 8, 8, 1), torch.eye(4).view(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r.vertex_map
+    pts = torch.rand(1, 10, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        icputils.point_to_plane_ICP(pts, pts, pts, torch.eye(4), numiters=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fusionutils.get_alpha(torch.rand(4, 3), 0.6)
+
+
+def test_product_does_not_import_the_oracle():
+    import subprocess
+    import sys
+
+    code = ("import sys, gradslam_amd; import gradslam_amd.slam, gradslam_amd.odometry; "
+            "print(any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules))")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO).decode().strip()
+    assert out == "False"
+    for root, _, files in os.walk(os.path.join(REPO, "gradslam_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+# ------------------------------------------------------------------ Pointclouds container
+def _pcs():
+    torch.manual_seed(0)
+    pts = [torch.rand(5, 3), torch.rand(3, 3)]
+    return gs.Pointclouds(pts, [p + 1 for p in pts], [p + 2 for p in pts], [torch.rand(5, 1), torch.rand(3, 1)]), pts
+
+
+def test_pointclouds_list_padded_views():
+    pc, pts = _pcs()
+    assert len(pc) == 2 and not pc.equisized and pc.num_features == 1
+    assert pc.points_padded.shape == (2, 5, 3) and torch.equal(pc.points_padded[1, :3], pts[1])
+    assert (pc.points_padded[1, 3:] == 0).all()
+    assert pc.nonpad_mask.tolist() == [[True] * 5, [True, True, True, False, False]]
+    assert pc.num_points_per_pointcloud.tolist() == [5, 3]
+    padded = gs.Pointclouds(torch.rand(2, 4, 3))
+    assert padded.equisized and [p.shape[0] for p in padded.points_list] == [4, 4]
+    assert not gs.Pointclouds().has_points and len(gs.Pointclouds()) == 0
+    sub = pc[1]
+    assert len(sub) == 1 and torch.equal(sub.points_list[0], pts[1])
+    assert len(pc[[0, 1]]) == 2 and len(pc[torch.tensor([True, False])]) == 1
+    with pytest.raises(IndexError):
+        gs.Pointclouds()[0]
+
+
+def test_pointclouds_append_and_setters():
+    pc, pts = _pcs()
+    other, _ = _pcs()
+    pc.append_points(other)
+    assert pc.num_points_per_pointcloud.tolist() == [10, 6] and pc.points_padded.shape == (2, 10, 3)
+    assert torch.equal(pc.points_list[1][3:], pts[1]) and pc.features_padded.shape == (2, 10, 1)
+    empty = gs.Pointclouds()
+    empty.append_points(other)
+    assert empty.has_points and empty.has_features and torch.equal(empty.points_list[0], pts[0])
+    bad = pc.points_padded.clone()
+    bad[1, -1] = 1.0
+    with pytest.raises(ValueError, match="value must have zeros wherever"):
+        pc.points_padded = bad
+    good = pc.points_padded * 2
+    pc.points_padded = good
+    assert torch.equal(pc.points_list[0], good[0])
+    with pytest.raises(ValueError, match="must either both have or not have normals"):
+        pc.append_points(gs.Pointclouds([torch.rand(1, 3), torch.rand(1, 3)]))
+    with pytest.raises(TypeError):
+        pc.append_points(3)
+    c = pc.clone()
+    c.points_padded = c.points_padded * 0
+    assert pc.points_padded.abs().sum() > 0
+    assert (pc + 1.0).points_list[0].allclose(pc.points_list[0] + 1.0)
+    assert pc.scale_(2.0).points_padded[1, -1].abs().sum() == 0
+
+
+def test_pointclouds_constructor_contracts():
+    with pytest.raises(TypeError, match="Expected points to be of type list or tensor or None"):
+        gs.Pointclouds(3)
+    with pytest.raises(TypeError, match="Expected normals to be of same type as points"):
+        gs.Pointclouds([torch.rand(2, 3)], torch.rand(1, 2, 3))
+    with pytest.raises(ValueError, match="last dim of all tensors in points should have shape 3"):
+        gs.Pointclouds([torch.rand(2, 4)])
+    with pytest.raises(ValueError, match="normals tensors should have same shape"):
+        gs.Pointclouds([torch.rand(2, 3)], [torch.rand(3, 3)])
+    with pytest.raises(ValueError, match=r"len\(points\) \(= 0\) should be > 0"):
+        gs.Pointclouds([])
+    with pytest.raises(ValueError, match="points should have ndim=3"):
+        gs.Pointclouds(torch.rand(4, 3))
+
+
+def test_pointclouds_transform_and_projection_algebra():
+    pc, pts = _pcs()
+    T = torch.eye(4)
+    T[:3, 3] = torch.tensor([1.0, 2.0, 3.0])
+    moved = pc.transform(T)
+    assert moved.points_list[1].allclose(pts[1] + T[:3, 3]) and (moved.points_padded[1, 3:] == 0).all()
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 10.0
+    proj = pc.pinhole_projection(K)
+    want = torch.stack([10 * pts[0][:, 0] / pts[0][:, 2], 10 * pts[0][:, 1] / pts[0][:, 2], torch.ones(5)], -1)
+    assert proj.points_list[0].allclose(want, rtol=1e-5)
+    with pytest.raises(ValueError, match="transform should be of shape"):
+        pc.transform(torch.eye(3))
+
+
+# ------------------------------------------------------------------ RGBDImages container
+def test_rgbdimages_contracts_and_indexing():
+    rgb, depth = torch.rand(2, 3, 8, 6, 3), torch.rand(2, 3, 8, 6, 1)
+    K = torch.eye(4).view(1, 1, 4, 4).repeat(2, 1, 1, 1)
+    poses = torch.eye(4).view(1, 1, 4, 4).repeat(2, 3, 1, 1)
+    r = gs.RGBDImages(rgb, depth, K, poses)
+    assert r.shape == (2, 3, 8, 6) and len(r) == 2 and r.cdim == 4 and r.has_poses
+    s = r[:, 1]
+    assert s.shape == (2, 1, 8, 6) and torch.equal(s.poses, poses[:, 1:2])
+    assert r[0].shape == (1, 3, 8, 6) and r[1, 0:2].shape == (1, 2, 8, 6)
+    with pytest.raises(IndexError):
+        r[5]
+    with pytest.raises(IndexError):
+        r[0, 0, 0]
+    with pytest.raises(TypeError, match="Expected rgb_image to be of type tensor"):
+        gs.RGBDImages(1, depth, K)
+    with pytest.raises(ValueError, match="rgb_image should have ndim=5"):
+        gs.RGBDImages(rgb[0], depth, K)
+    with pytest.raises(ValueError, match="Expected depth_image to have shape"):
+        gs.RGBDImages(rgb, depth[:, :2], K)
+    with pytest.raises(ValueError, match="Expected intrinsics to have shape"):
+        gs.RGBDImages(rgb, depth, K[:1])
+    assert torch.equal(r.valid_depth_mask, depth > 0)
+    cf = r.to_channels_first()
+    assert cf.channels_first and cf.rgb_image.shape == (2, 3, 3, 8, 6)
+    assert cf.to_channels_last().rgb_image.shape == rgb.shape
+    r._vertex_map = torch.zeros(2, 3, 8, 6, 3)
+    r._global_vertex_map = torch.zeros(2, 3, 8, 6, 3)
+    r.poses = poses * 1
+    assert r._global_vertex_map is None and r._vertex_map is not None
+    r.intrinsics = K * 1
+    assert r._vertex_map is None
+    with pytest.raises(ValueError):
+        r.poses = poses[:, :1]
+
+
+# ------------------------------------------------------------------ error contracts of the path
+def test_icputils_error_contracts():
+    A, b = torch.rand(5, 6), torch.rand(5, 1)
+    with pytest.raises(TypeError, match="Expected A to be of type torch.Tensor"):
+        icputils.solve_linear_system(1, b)
+    with pytest.raises(TypeError, match="Expected damp to be of type float or torch.Tensor"):
+        icputils.solve_linear_system(A, b, 1)
+    with pytest.raises(ValueError, match=r"b.shape\[1\] should 1"):
+        icputils.solve_linear_system(A, torch.rand(5, 2))
+    with pytest.raises(ValueError, match=r"A.shape\[0\] and b.shape\[0\] should be equal"):
+        icputils.solve_linear_system(A, torch.rand(4, 1))
+    A = torch.rand(50, 6)
+    x = icputils.solve_linear_system(A, A @ torch.ones(6, 1), 1e-8)  # O(1) algebra: runs anywhere
+    assert torch.allclose(x, torch.ones(6, 1), atol=1e-3)
+    p = torch.rand(1, 7, 3)
+    with pytest.raises(TypeError, match="Expected dist_thresh to be of type float or int"):
+        icputils.gauss_newton_solve(p, p, p, "x")
+    with pytest.raises(ValueError, match="src_pc should have ndim=3"):
+        icputils.gauss_newton_solve(p[0], p, p)
+    with pytest.raises(ValueError, match=r"tgt_pc.shape\[1\] and tgt_normals.shape\[1\] must be equal"):
+        icputils.gauss_newton_solve(p, p, p[:, :5])
+    with pytest.raises(TypeError, match="Expected numiters to be of type int"):
+        icputils.point_to_plane_ICP(p, p, p, torch.eye(4), numiters=2.0)
+    with pytest.raises(ValueError, match=r"Expected initial_transform.shape to be \(4, 4\)"):
+        icputils.point_to_plane_ICP(p, p, p, torch.eye(3))
+    with pytest.raises(TypeError, match="Expected lambda_max to be of type float or int"):
+        icputils.point_to_plane_gradICP(p, p, p, torch.eye(4), lambda_max="2")
+    pc = gs.Pointclouds([torch.rand(4, 3)])
+    with pytest.raises(TypeError, match="Expected pointclouds to be of type gradslam.Pointclouds"):
+        icputils.downsample_pointclouds(3, torch.zeros(1, 4, dtype=torch.int64), 2)
+    with pytest.raises(ValueError, match=r"pc2im_bnhw.shape\[1\] must be 4"):
+        icputils.downsample_pointclouds(pc, torch.zeros(1, 3, dtype=torch.int64), 2)
+    with pytest.raises(TypeError, match="Expected ds_ratio to be of type int"):
+        icputils.downsample_pointclouds(pc, torch.zeros(1, 4, dtype=torch.int64), 2.0)
+
+
+def test_provider_and_slam_contracts():
+    pts = torch.tensor([[5.0, 5.0, 5.0], [3.0, 3.0, 3.0]])
+    for prov in (gs.odometry.ICPOdometryProvider(), gs.odometry.GradICPOdometryProvider()):
+        with pytest.raises(ValueError, match="maps_pointclouds missing normals"):
+            prov.provide(gs.Pointclouds([pts]), gs.Pointclouds([pts], [pts]))
+        with pytest.raises(ValueError, match="Batch size of maps_pointclouds and frames_pointclouds should be equal"):
+            prov.provide(gs.Pointclouds([pts], [pts]), gs.Pointclouds([pts, pts], [pts, pts]))
+        with pytest.raises(TypeError, match="Expected maps_pointclouds to be of type gradslam.Pointclouds"):
+            prov.provide(1, gs.Pointclouds([pts]))
+    with pytest.raises(ValueError, match="not supported for PointFusion"):
+        gs.slam.ICPSLAM(odom="xyz")
+    with pytest.raises(TypeError, match="Distance threshold must be of type float or int"):
+        gs.slam.PointFusion(dist_th="a")
+    with pytest.warns(UserWarning, match="Angle threshold"):
+        gs.slam.PointFusion(angle_th=120)
+    slam = gs.slam.PointFusion(odom="icp")
+    assert slam.dsratio == 4 and abs(slam.dot_th - 0.9396926) < 1e-6 and slam.sigma == 0.6
+    with pytest.raises(TypeError, match="Expected frames to be of type gradslam.RGBDImages"):
+        slam(3)
+    r = gs.RGBDImages(torch.rand(1, 1, 4, 4, 3), torch.rand(1, 1, 4, 4, 1), torch.eye(4).view(1, 1, 4, 4))
+    with pytest.raises(ValueError, match="`live_frame` must have poses"):
+        slam._localize(gs.Pointclouds(), r, None)
+    with pytest.raises(TypeError, match="Expected prev_frame to be of type gradslam.RGBDImages or None"):
+        slam._localize(gs.Pointclouds(), r, 3)
+
+
+def test_fusionutils_error_contracts():
+    pc = gs.Pointclouds([torch.rand(4, 3)])
+    r = gs.RGBDImages(torch.rand(1, 2, 4, 4, 3), torch.rand(1, 2, 4, 4, 1), torch.eye(4).view(1, 1, 4, 4),
+                      torch.eye(4).view(1, 1, 4, 4).repeat(1, 2, 1, 1))
+    tab = torch.zeros(2, 4, dtype=torch.int64)
+    with pytest.raises(TypeError, match="Expected pointclouds to be of type gradslam.Pointclouds"):
+        fusionutils.find_active_map_points(1, r)
+    with pytest.raises(ValueError, match="Expected rgbdimages to have sequence length of 1"):
+        fusionutils.find_active_map_points(pc, r)
+    assert fusionutils.find_active_map_points(gs.Pointclouds(), r[:, 0]).shape == (0, 4)
+    with pytest.raises(TypeError, match="Expected input pc2im_bnhw to have dtype of"):
+        fusionutils.find_similar_map_points(pc, r[:, 0], tab.int(), 0.1, 0.5)
+    with pytest.raises(ValueError, match="Expected pc2im_bnhw.ndim of 2"):
+        fusionutils.find_similar_map_points(pc, r[:, 0], tab[0], 0.1, 0.5)
+    with pytest.raises(ValueError, match="Pointclouds must have normals"):
+        fusionutils.find_similar_map_points(pc, r[:, 0], tab, 0.1, 0.5)
+    with pytest.raises(ValueError, match="Pointclouds must have features"):
+        fusionutils.find_best_unique_correspondences(pc, r[:, 0], tab)
+    with pytest.raises(ValueError, match="Pointclouds must have normals for map fusion"):
+        fusionutils.fuse_with_map(pc, r[:, 0], tab, 0.6)
+    with pytest.raises(TypeError, match="Expected input sigma to be of type"):
+        fusionutils.get_alpha(torch.rand(3, 3), "s")
+    with pytest.raises(ValueError, match="dimension to be 3"):
+        fusionutils.get_alpha(torch.rand(3, 4), 0.6)
+    with pytest.raises(ValueError, match="tensor1 and tensor2 should have the same shape"):
+        fusionutils.are_points_close(torch.rand(3, 3), torch.rand(2, 3), 0.1)
+    with pytest.warns(RuntimeWarning, match="Max of dot product was"):
+        fusionutils.are_normals_similar(torch.ones(2, 3) * 2, torch.ones(2, 3), 0.5)
+    assert fusionutils.are_points_close(torch.zeros(2, 3), torch.zeros(2, 3) + 0.01, 0.05).all()
+
+
+# ------------------------------------------------------------------ geometry helpers
+def test_se3_and_rigid_algebra():
+    from gradslam_amd.geometry import geometryutils as gu
+    from gradslam_amd.geometry import se3utils
+
+    T = se3utils.se3_exp(torch.tensor([0.1, -0.2, 0.3, 0.3, 0.2, -0.1]))
+    assert torch.allclose(T[:3, :3] @ T[:3, :3].t(), torch.eye(3), atol=1e-6) and T[3].tolist() == [0, 0, 0, 1]
+    Ti = gu.inverse_transformation(T)
+    assert torch.allclose(gu.compose_transformations(T, Ti), torch.eye(4), atol=1e-6)
+    assert torch.allclose(gu.relative_transformation(T, T), torch.eye(4), atol=1e-5)
+    small = se3utils.se3_exp(torch.tensor([1.0, 2.0, 3.0, 1e-8, 0.0, 0.0]))
+    assert torch.allclose(small[:3, 3], torch.tensor([1.0, 2.0, 3.0]), atol=1e-6)
+    g = gu.create_meshgrid(3, 4, normalized_coords=False)
+    assert g.shape == (1, 3, 4, 2) and g[0, 2, 3].tolist() == [2.0, 3.0]
