@@ -199,13 +199,13 @@ def main():
             "config": {"workload": "c2: ICP odometry localisation step, 640x480 TUM-shape synthetic RGB-D, batch 1 per GPU, "
                                    "dsratio 4 (~19k x ~19k points), 10 LM iterations, map {} points".format(n_map),
                        "parallelism": "one sequence per GPU, final RCCL all_gather of poses", "pose_max_abs_err": pose_err},
-            "roofline": {"kernel": "knn1_sel_k (exact 1-NN association)", "bound": "mfma", "achieved": round(ach, 2),
+            "roofline": {"kernel": "knn1_loop_k (exact 1-NN association, AABB-pruned)", "bound": "mfma", "achieved": round(ach, 2),
                          "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
                          "launches": n_knn, "avg_launch_ms": round(avg_knn_ms, 5), "flops_per_launch": flops,
                          "note": "FP32-VALU-bound kernel (no dense contraction, MFMA unused); 157.3 TFLOP/s is the FP32 "
                                  "peak of both the vector and the f32 matrix pipe; 8 flop per src x tgt pair, ~19.2k x ~19.2k "
                                  "pairs upper bound per launch"},
-            "roofline_linearize_c2": {"kernel": "linearize_sel_k", "launches": n_lin,
+            "roofline_linearize_c2": {"kernel": "linearize_loop_k", "launches": n_lin,
                                       "avg_launch_ms": round(ms_lin / max(n_lin, 1), 5),
                                       "note": "0.77 MB per launch: L2-resident, launch-bound -- not an HBM measurement"},
         }

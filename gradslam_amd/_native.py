@@ -37,14 +37,16 @@ SIGNATURES = {
     "gs_gather_table_rows_ws_bytes": (c_sz, [c_i]),
     "gs_gather_table_rows": (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_table_ds_mask": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
-    "gs_knn1": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
+    "gs_knn1_ws_bytes": (c_sz, [c_i]),
+    "gs_knn1": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_sz, c_p]),
+    "gs_knn1_bruteforce": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
     "gs_knn1_unpack": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
     "gs_icp_linearize_ws_bytes": (c_sz, [c_i]),
     "gs_icp_linearize": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_sz, c_p]),
     "gs_icp_rows": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     "gs_icp_linearize_backward": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "gs_transform_points": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
-    "gs_icp_ws_bytes": (c_sz, [c_i]),
+    "gs_icp_ws_bytes": (c_sz, [c_i, c_i]),
     "gs_icp_point_to_plane": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_sz,
                                     c_p]),
     "gs_icp_point_to_plane_grad": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f,

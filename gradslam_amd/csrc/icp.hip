@@ -1,88 +1,219 @@
 // icp.hip -- exact 1-NN association (K), linearise + 6x6 reduce (J), the O(1) solve / SE(3)
 // exponential / LM control (X), and whole ICP / gradICP loops that never leave the device.
 //
-// K is FP32-VALU bound (8 flop per src x tgt pair, no dense contraction -> no MFMA; an
-// |p|^2+|q|^2-2p.q MFMA form would change rounding and tie-breaks).  The target cloud is read with
-// wave-uniform addresses, so it streams through the scalar cache into SGPRs and costs no VGPRs or LDS
-// bandwidth; the launch is split over (source tiles) x (target ranges) to fill 256 CUs even when
-// there are only ~19 k source points, and partial winners are merged with one 64-bit atomic min
-// per (point, range) on the packed key  dist_bits<<32 | index  (min distance, then lowest index:
-// exactly the reference's strict-< scan order).
-// J is a gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; it
-// reduces with wave butterflies and a fixed-order two-level tree (deterministic, no float atomics).
+// K  The reference's association is an exact K=1 nearest-neighbour search (squared L2 accumulated
+//    x->y->z in fp32 without FMA, strict '<' so the lowest index wins ties).  Two kernels compute it:
+//    * knn1_brute_k: every (source, target) pair.  FP32-VALU bound (8 flop/pair, no dense contraction
+//      -> no MFMA; a |p|^2+|q|^2-2p.q matrix form would change rounding and tie-breaks).  Target points
+//      are read with wave-uniform addresses, so they stream through the scalar cache into SGPRs.
+//    * knn1_box_k / knn1_loop_k (the ones the ICP loops use): the same pairs, minus those that provably
+//      cannot win.  Target points are grouped in chunks of 64 consecutive points (image order =>
+//      spatially compact) with an AABB each.  A wave owns 64 source points, seeds each lane's best with
+//      one real candidate (the previous iteration's neighbour, or the point at the same relative index),
+//      and skips a chunk iff every lane's fp32 lower bound ((ex^2+ey^2)+ez^2, e = per-axis distance to
+//      the box) is STRICTLY greater than that lane's current best.  Rounding is monotone and the bound
+//      uses the same operation order as the distance, so bound <= distance holds exactly in fp32: no
+//      epsilon, and the result is bit-identical to the brute-force scan (lexicographic (distance, index)
+//      minimum).
+//    Both split the target range over blockIdx.y to fill 256 CUs with ~19 k source points and merge
+//    with one 64-bit atomic min per (point, range) on the packed key  dist_bits<<32 | index.
+// J  gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; wave
+//    butterflies + a fixed-order two-level tree (deterministic, no float atomics).
+// X  one small workgroup per iteration: reduce the partials, LM / gradLM decision, fp64 6x6 solve,
+//    SE(3) exponential.  Buffers are addressed through device-side role indices, so accept/reject needs
+//    no host round trip and no copies.
 #include <vector>
 
 #include "gs_common.hpp"
 
 namespace gs {
 
-constexpr int KNN_T = 256;   // threads per block
-constexpr int KNN_SPT = 2;   // source points per thread
-constexpr int KNN_TILE = KNN_T * KNN_SPT;
-constexpr int NACC = 29;     // 21 (upper H) + 6 (g) + e + count
+constexpr int KNN_T = 256;      // threads per block (4 waves, one 64-point source tile each)
+constexpr int CHUNK = 64;       // target points per AABB chunk
+constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
 constexpr int LIN_MAXB = 1024;  // max partial blocks
+constexpr unsigned long long KEY_NONE = ~0ull;
 
-// ------------------------------------------------------------------ K
-// src_in -> (optional rigid transform by the DEVICE 4x4 `T`) -> src_out (written by range 0 only)
-// -> nearest target in this block's target range -> atomic min into best[].
-__global__ __launch_bounds__(KNN_T) void knn1_k(const float *__restrict__ src_in, const int32_t *__restrict__ d_ns,
-                                                const float *__restrict__ T, float *__restrict__ src_out,
-                                                const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
-                                                int nsplit, unsigned long long *__restrict__ best) {
+__device__ __forceinline__ unsigned long long pack_key(float d, int j) {
+    return ((unsigned long long)fbits(d) << 32) | (unsigned int)j;
+}
+__device__ __forceinline__ float dist2(f3 s, float tx, float ty, float tz) {
+    const float dx = s.x - tx, dy = s.y - ty, dz = s.z - tz;
+    return (dx * dx + dy * dy) + dz * dz;  // contraction off: x->y->z, no fma
+}
+
+// ------------------------------------------------------------------ K: brute force (verifier / tiny inputs)
+__global__ __launch_bounds__(KNN_T) void knn1_brute_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
+                                                      const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
+                                                      int nsplit, unsigned long long *__restrict__ best) {
     const int ns = *d_ns, nt = *d_nt;
-    const int tile0 = blockIdx.x * KNN_TILE;
-    if (tile0 >= ns) return;
-    // this block's target range
+    const int i = blockIdx.x * KNN_T + threadIdx.x;
+    if (blockIdx.x * KNN_T >= ns) return;
     const int chunk = (nt + nsplit - 1) / nsplit;
-    const int j0 = blockIdx.y * chunk;
-    const int j1 = min(nt, j0 + chunk);
+    const int j0 = blockIdx.y * chunk, j1 = min(nt, j0 + chunk);
+    const bool ok = i < ns;
+    const f3 s = ok ? ld3(src, i) : f3{0.0f, 0.0f, 0.0f};
+    float bd = INFINITY;
+    int bi = 0;
+    for (int j = j0; j < j1; ++j) {  // wave-uniform j: tgt[j] lives in SGPRs
+        const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
+        if (d < bd) { bd = d; bi = j; }  // strict: lowest index wins
+    }
+    if (ok && bd < INFINITY) atomicMin(best + i, pack_key(bd, bi));
+}
 
-    float sx[KNN_SPT], sy[KNN_SPT], sz[KNN_SPT], bd[KNN_SPT];
-    int bi[KNN_SPT];
-    bool ok[KNN_SPT];
-#pragma unroll
-    for (int k = 0; k < KNN_SPT; ++k) {
-        const int i = tile0 + k * KNN_T + threadIdx.x;
-        ok[k] = i < ns;
-        f3 p{0.0f, 0.0f, 0.0f};
-        if (ok[k]) {
-            p = ld3(src_in, i);
-            if (T) {
-                p = xform(T, p);
-                if (src_out && blockIdx.y == 0) st3(src_out, i, p);
-            }
-        }
-        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
-        bd[k] = INFINITY;
-        bi[k] = 0;
-    }
-    if (j0 >= j1) return;
-    // wave-uniform j: the compiler keeps tgt[j] in SGPRs (s_load), VALU ops read them directly
-    for (int j = j0; j < j1; ++j) {
-        const float tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
-#pragma unroll
-        for (int k = 0; k < KNN_SPT; ++k) {
-            const float dx = sx[k] - tx, dy = sy[k] - ty, dz = sz[k] - tz;
-            const float d = (dx * dx + dy * dy) + dz * dz;  // contract off: x->y->z, no fma
-            if (d < bd[k]) { bd[k] = d; bi[k] = j; }        // strict: lowest index wins
-        }
+// ------------------------------------------------------------------ K: AABB-pruned exact search
+// boxes: per chunk 6 floats (lo.xyz, hi.xyz)
+__global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
+                                                  float *__restrict__ boxes) {
+    const int nt = *d_nt;
+    const int c = blockIdx.x;
+    const int j = c * CHUNK + threadIdx.x;
+    if (c * CHUNK >= nt) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (j < nt) {
+        const f3 p = ld3(tgt, j);
+        lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
     }
 #pragma unroll
-    for (int k = 0; k < KNN_SPT; ++k) {
-        if (!ok[k] || !(bd[k] < INFINITY)) continue;
-        const int i = tile0 + k * KNN_T + threadIdx.x;
-        const unsigned long long key = ((unsigned long long)fbits(bd[k]) << 32) | (unsigned int)bi[k];
-        atomicMin(best + i, key);
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, kWave));
+        }
+    }
+    if (threadIdx.x == 0) {
+        float *b = boxes + 6 * c;
+        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
     }
 }
 
+// Search chunks [c0, c1) for the lane's point s.  (bd, bi) carry the running lexicographic best.
+__device__ __forceinline__ void box_search(const f3 s, const bool ok, const float *__restrict__ tgt,
+                                           const float *__restrict__ boxes, int nt, int c0, int c1, float &bd, int &bi) {
+    for (int c = c0; c < c1; ++c) {
+        const float *b = boxes + 6 * c;  // wave-uniform -> scalar loads
+        // per-axis distance to the box, then the SAME accumulation order as dist2 (monotone rounding
+        // => lower bound holds exactly in fp32)
+        const float ex = fmaxf(fmaxf(b[0] - s.x, s.x - b[3]), 0.0f);
+        const float ey = fmaxf(fmaxf(b[1] - s.y, s.y - b[4]), 0.0f);
+        const float ez = fmaxf(fmaxf(b[2] - s.z, s.z - b[5]), 0.0f);
+        const float lb = (ex * ex + ey * ey) + ez * ez;
+        if (!__any(ok && lb <= bd)) continue;  // every lane: bound strictly above its best -> skip
+        const int j0 = c * CHUNK, j1 = min(nt, j0 + CHUNK);
+        for (int j = j0; j < j1; ++j) {
+            const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
+            if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }  // (distance, index) lexicographic
+        }
+    }
+}
+
+// Device-resident loop state.  Point clouds ping-pong between pts[0..1]; nearest-neighbour buffers
+// rotate through best[0..2] (current / in flight / being cleared).
+struct IcpState {
+    float T[16];    // accumulated transform
+    float dT[16];   // step the next association launch applies
+    float cur[44];  // H|g|e|cnt of the current cloud
+    float xi[6];
+    float damp;
+    int p_cur;      // pts[p_cur] = current cloud; the association writes pts[1 - p_cur]
+    int b_cur;      // best[b_cur] = NN of the current cloud
+    int b_look;     // best[b_look]: written by the association in flight (pre-cleared)
+    int b_spare;    // best[b_spare]: cleared by the linearise launch in flight
+    int b_first;    // NN buffer of the cloud the last iteration's first solve used
+    int it;
+};
+
+struct LoopBufs {
+    float *pts[2];
+    unsigned long long *best[3];
+};
+
+// Association launch of the loops: in = (first ? user source : pts[p_cur]) transformed by S->dT,
+// out = pts[1 - p_cur], NN -> best[b_look].  Seeds: the current cloud's NN (same source index) when
+// there is one, else the target at the same relative index.
+__global__ __launch_bounds__(KNN_T) void knn1_loop_k(const IcpState *__restrict__ S, int first,
+                                                     const float *__restrict__ user_src, LoopBufs B,
+                                                     const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                                                     const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
+                                                     int nsplit) {
+    const int ns = *d_ns, nt = *d_nt;
+    const int wave = threadIdx.x >> 6;
+    const int tile0 = (blockIdx.x * (KNN_T / 64) + wave) * 64;
+    if (tile0 >= ns || nt <= 0) return;
+    const int p_cur = S->p_cur;
+    const float *in = first ? user_src : B.pts[p_cur];
+    float *out = B.pts[1 - p_cur];
+    unsigned long long *best = B.best[S->b_look];
+    const unsigned long long *seed = first ? nullptr : B.best[S->b_cur];
+    const int i = tile0 + (threadIdx.x & 63);
+    const bool ok = i < ns;
+    f3 s{0.0f, 0.0f, 0.0f};
+    if (ok) {
+        s = xform(S->dT, ld3(in, i));
+        if (blockIdx.y == 0) st3(out, i, s);
+    }
+    // seed with one real candidate
+    int sj = 0;
+    if (ok) {
+        if (seed) {
+            const unsigned long long k = seed[i];
+            sj = (k == KEY_NONE) ? 0 : (int)(uint32_t)(k & 0xffffffffu);
+        } else {
+            sj = (int)(((long long)i * nt) / ns);
+        }
+        sj = min(max(sj, 0), nt - 1);
+    }
+    float bd = INFINITY;
+    int bi = 0;
+    if (ok) {
+        const f3 q = ld3(tgt, sj);
+        bd = dist2(s, q.x, q.y, q.z);
+        bi = sj;
+    }
+    const int nchunks = (nt + CHUNK - 1) / CHUNK;
+    const int per = (nchunks + nsplit - 1) / nsplit;
+    const int c0 = blockIdx.y * per, c1 = min(nchunks, c0 + per);
+    box_search(s, ok, tgt, boxes, nt, c0, c1, bd, bi);
+    // range 0 always posts (it carries the seed candidate); the others only if they beat the seed
+    if (ok && (blockIdx.y == 0 || bi != sj)) atomicMin(best + i, pack_key(bd, bi));
+}
+
+// Stand-alone pruned search (gs_knn1): no transform, seed = same relative index.
+__global__ __launch_bounds__(KNN_T) void knn1_box_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
+                                                    const float *__restrict__ tgt, const float *__restrict__ boxes,
+                                                    const int32_t *__restrict__ d_nt, int nsplit,
+                                                    unsigned long long *__restrict__ best) {
+    const int ns = *d_ns, nt = *d_nt;
+    const int wave = threadIdx.x >> 6;
+    const int tile0 = (blockIdx.x * (KNN_T / 64) + wave) * 64;
+    if (tile0 >= ns || nt <= 0) return;
+    const int i = tile0 + (threadIdx.x & 63);
+    const bool ok = i < ns;
+    const f3 s = ok ? ld3(src, i) : f3{0.0f, 0.0f, 0.0f};
+    float bd = INFINITY;
+    int bi = 0, sj = 0;
+    if (ok) {
+        sj = min(max((int)(((long long)i * nt) / ns), 0), nt - 1);
+        const f3 q = ld3(tgt, sj);
+        bd = dist2(s, q.x, q.y, q.z);
+        bi = sj;
+    }
+    const int nchunks = (nt + CHUNK - 1) / CHUNK;
+    const int per = (nchunks + nsplit - 1) / nsplit;
+    const int c0 = blockIdx.y * per, c1 = min(nchunks, c0 + per);
+    box_search(s, ok, tgt, boxes, nt, c0, c1, bd, bi);
+    if (ok && (blockIdx.y == 0 || bi != sj)) atomicMin(best + i, pack_key(bd, bi));
+}
+
 __global__ void knn_unpack_k(const unsigned long long *__restrict__ best, const int32_t *__restrict__ d_ns,
-                             float *__restrict__ dist2, int64_t *__restrict__ idx) {
+                             float *__restrict__ dist2_out, int64_t *__restrict__ idx) {
     const int ns = *d_ns;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
         const unsigned long long k = best[i];
-        if (dist2) dist2[i] = bitsf((uint32_t)(k >> 32));
+        if (dist2_out) dist2_out[i] = bitsf((uint32_t)(k >> 32));
         if (idx) idx[i] = (int64_t)(uint32_t)(k & 0xffffffffu);
     }
 }
@@ -106,10 +237,10 @@ __device__ __forceinline__ Row make_row(const float *__restrict__ src, const flo
     r.valid = false;
     if (i >= ns) return r;
     const unsigned long long key = best[i];
+    if (key == KEY_NONE) return r;  // no target at all
     const uint32_t j = (uint32_t)(key & 0xffffffffu);
     const float d2 = bitsf((uint32_t)(key >> 32));
-    if (key == ~0ull) return r;                       // no target at all
-    if (thresh >= 0.0f && !(d2 < thresh)) return r;   // NB squared distance vs threshold
+    if (thresh >= 0.0f && !(d2 < thresh)) return r;  // NB squared distance vs threshold
     const f3 s = ld3(src, i), d = ld3(tgt, j), n = ld3(nrm, j);
     r.a[0] = n.x; r.a[1] = n.y; r.a[2] = n.z;
     r.a[3] = n.z * s.y - n.y * s.z;
@@ -120,27 +251,20 @@ __device__ __forceinline__ Row make_row(const float *__restrict__ src, const flo
     return r;
 }
 
-__global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
-                                                     const float *__restrict__ tgt, const float *__restrict__ nrm,
-                                                     const unsigned long long *__restrict__ best, float thresh,
-                                                     float *__restrict__ partials /* gridDim.x x NACC */) {
-    const int ns = *d_ns;
-    float acc[NACC];
+__device__ __forceinline__ void accumulate_row(const Row &r, float *acc) {
+    int q = 0;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
-        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
-        if (!r.valid) continue;
-        int q = 0;
+    for (int u = 0; u < 6; ++u)
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
+        for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
 #pragma unroll
-            for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
-        acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
-        acc[28] += 1.0f;
-    }
+    for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
+    acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
+    acc[28] += 1.0f;
+}
+
+// block-level fixed-order reduction of the 29 accumulators -> partials[blockIdx.x]
+__device__ __forceinline__ void block_reduce_store(float *acc, float *__restrict__ partials) {
     __shared__ float sm[LIN_T / 64][NACC];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -157,13 +281,51 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
     }
 }
 
-// fixed-order reduction of the per-block partials; 64 threads (one wave)
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm /*NACC*/) {
-    const int t = threadIdx.x;
-    if (t < NACC) {
+__global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
+                                                     const float *__restrict__ tgt, const float *__restrict__ nrm,
+                                                     const unsigned long long *__restrict__ best, float thresh,
+                                                     float *__restrict__ partials /* gridDim.x x NACC */) {
+    const int ns = *d_ns;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
+        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
+        if (r.valid) accumulate_row(r, acc);
+    }
+    block_reduce_store(acc, partials);
+}
+
+// linearise the cloud the association launch just produced (pts[1-p_cur], best[b_look]) and clear
+// best[b_spare] for the launch after next
+__global__ __launch_bounds__(LIN_T) void linearize_loop_k(const IcpState *__restrict__ S, LoopBufs B,
+                                                          const int32_t *__restrict__ d_ns, int max_ns,
+                                                          const float *__restrict__ tgt, const float *__restrict__ nrm,
+                                                          float thresh, float *__restrict__ partials) {
+    const float *src = B.pts[1 - S->p_cur];
+    const unsigned long long *best = B.best[S->b_look];
+    unsigned long long *spare = B.best[S->b_spare];
+    const int ns = *d_ns;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < max_ns; i += gridDim.x * LIN_T) {
+        spare[i] = KEY_NONE;
+        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
+        if (r.valid) accumulate_row(r, acc);
+    }
+    block_reduce_store(acc, partials);
+}
+
+// Fixed-order reduction of the per-block partials by all waves of the block into acc_sm[NACC]:
+// wave w owns accumulators w, w+nw, ...; lanes stride over the partial blocks, then butterfly.
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wid; k < NACC; k += nw) {
         float v = 0.0f;
-        for (int b = 0; b < nblocks; ++b) v += partials[b * NACC + t];
-        acc_sm[t] = v;
+        for (int b = lane; b < nblocks; b += 64) v += partials[b * NACC + k];
+        v = wave_sum(v);
+        if (lane == 0) acc_sm[k] = v;
     }
     __syncthreads();
 }
@@ -178,7 +340,7 @@ __device__ __forceinline__ void expand44(const float *acc, float *out44) {
     out44[43] = acc[28];
 }
 
-__global__ __launch_bounds__(64) void finalize44_k(const float *__restrict__ partials, int nblocks, float *__restrict__ out44) {
+__global__ __launch_bounds__(1024) void finalize44_k(const float *__restrict__ partials, int nblocks, float *__restrict__ out44) {
     __shared__ float acc[NACC];
     reduce_partials(partials, nblocks, acc);
     if (threadIdx.x == 0) expand44(acc, out44);
@@ -226,7 +388,7 @@ __global__ void linearize_bwd_k(const float *__restrict__ src, const int32_t *__
         float bb = 2.0f * G[42] * r.b;
 #pragma unroll
         for (int u = 0; u < 6; ++u) bb += G[36 + u] * r.a[u];
-        // a = [n ; s x n]  (a[3..5] = (n.z s.y - n.y s.z, n.x s.z - n.z s.x, n.y s.x - n.x s.y) = s x n)
+        // a = [n ; s x n]
         const f3 an{ab[0], ab[1], ab[2]}, ac{ab[3], ab[4], ab[5]};
         // c = s x n: s_bar = n x c_bar ; n_bar += c_bar x s
         f3 sb{n.y * ac.z - n.z * ac.y, n.z * ac.x - n.x * ac.z, n.x * ac.y - n.y * ac.x};
@@ -266,9 +428,9 @@ __device__ void solve6(const float *H, const float *g, float damp, float *x) {
     }
     for (int c = 0; c < 6; ++c) {
         int p = c;
-        double best = fabs(M[c][c]);
+        double big = fabs(M[c][c]);
         for (int r = c + 1; r < 6; ++r)
-            if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+            if (fabs(M[r][c]) > big) { big = fabs(M[r][c]); p = r; }
         if (p != c)
             for (int k = 0; k < 7; ++k) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
         const double piv = M[c][c];
@@ -328,20 +490,7 @@ __device__ void mm4(const float *A, const float *B, float *C) {
     for (int i = 0; i < 16; ++i) C[i] = r[i];
 }
 
-// Device-resident loop state.  Two source-cloud buffers / NN buffers ping-pong; `sel` says which
-// one is the current cloud.
-struct IcpState {
-    float T[16];      // accumulated transform
-    float dT[16];     // step handed to the next association launch
-    float cur[44];    // H|g|e|cnt of the current cloud
-    float xi[6];
-    float damp;
-    int sel;          // current cloud = buf[sel]
-    int sel_first;    // buffer that held the cloud of the last iteration's first solve
-    int it;
-};
-
-enum StepMode { STEP_INIT = 0, STEP_LM = 1, STEP_GRAD_A = 2, STEP_GRAD_B = 3 };
+enum StepMode { STEP_ADOPT = 0, STEP_LM = 1, STEP_GRAD_B = 2 };
 
 struct GradParams {
     // formed in double on the host like the reference's Python scalars, rounded once:
@@ -349,219 +498,120 @@ struct GradParams {
     float lambda_min, range, B, B2, inv_nu;
 };
 
-// One wave.  Reduces the partials of the association+linearise launch that just ran and advances
-// the LM / gradLM state machine; fills best[] of the buffer the NEXT launch will write with the
-// all-ones key.
-//   STEP_INIT  : partials describe the initial cloud      -> cur = lin ; solve ; dT = exp(xi)
-//   STEP_LM    : partials describe the look-ahead cloud   -> accept/reject ; solve ; dT = exp(xi)
-//   STEP_GRAD_A: partials describe the current cloud      -> cur = lin ; solve ; dT = exp(xi)
-//   STEP_GRAD_B: partials describe the look-ahead cloud   -> damp, sigma ; dT = exp(sigma xi) ; T = dT T
-__global__ __launch_bounds__(64) void icp_step_k(IcpState *__restrict__ S, const float *__restrict__ partials, int nblocks,
-                                                 int mode, int last, GradParams gp, float *__restrict__ trace /* or NULL */,
-                                                 unsigned long long *__restrict__ bestA,
-                                                 unsigned long long *__restrict__ bestB, int max_ns,
-                                                 float *__restrict__ out_T /* or NULL: written every step */) {
+__device__ __forceinline__ void adopt_look(IcpState *S, const float *lin) {
+    for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
+    S->p_cur = 1 - S->p_cur;
+    const int old = S->b_cur;
+    S->b_cur = S->b_look;
+    S->b_look = S->b_spare;  // cleared by the linearise launch that just ran
+    S->b_spare = old;
+}
+__device__ __forceinline__ void discard_look(IcpState *S) {
+    const int t = S->b_look;
+    S->b_look = S->b_spare;
+    S->b_spare = t;
+}
+
+// Reduces the partials of the association + linearise launches that just ran and advances the LM /
+// gradLM state machine.
+//   STEP_ADOPT : the look-ahead cloud becomes the current one unconditionally (initial cloud; gradICP's
+//                re-linearisation)                          -> solve ; dT = exp(xi)
+//   STEP_LM    : look-ahead cloud: accept (adopt, damp/2, T = dT T) or reject (damp*2) -> solve ; dT
+//   STEP_GRAD_B: look-ahead error -> damp, sigma ; dT = exp(sigma xi) ; T = dT T ; look-ahead discarded
+__global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ S, const float *__restrict__ partials, int nblocks,
+                                                  int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
+                                                  float *__restrict__ out_T) {
     __shared__ float acc[NACC];
-    __shared__ int s_next_fill;
     reduce_partials(partials, nblocks, acc);
-    if (threadIdx.x == 0) {
-        float lin[44];
-        expand44(acc, lin);
-        int fill = -1;  // which best buffer the next association launch writes
-        if (mode == STEP_INIT || mode == STEP_GRAD_A) {
-            for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
-            solve6(S->cur, S->cur + 36, S->damp, S->xi);
-            se3_exp_dev(S->xi, S->dT);
-            S->sel_first = S->sel;
-            fill = 1 - S->sel;  // look-ahead goes to the other buffer
-        } else if (mode == STEP_LM) {
-            const float err = S->cur[42], new_err = lin[42];
-            const bool accept = new_err < err;
-            if (trace) {
-                float *t = trace + 48 * S->it;
-                for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
-                t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = accept ? 1.0f : 0.0f; t[46] = S->cur[43];
-                t[47] = 0.0f;
-            }
-            S->sel_first = S->sel;
-            if (accept) {
-                S->sel = 1 - S->sel;
-                for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
-                S->damp = S->damp / 2.0f;
-                mm4(S->dT, S->T, S->T);
-            } else {
-                S->damp = S->damp * 2.0f;
-            }
-            S->it += 1;
-            solve6(S->cur, S->cur + 36, S->damp, S->xi);
-            se3_exp_dev(S->xi, S->dT);
-            fill = 1 - S->sel;
-        } else {  // STEP_GRAD_B
-            const float err = S->cur[42], new_err = lin[42];
-            float diff = new_err - err;
-            diff = fminf(fmaxf(diff, -70.0f), 70.0f);
-            const float damp_new = gp.lambda_min + gp.range / (1.0f + expf((-gp.B) * diff));
-            if (trace) {
-                float *t = trace + 48 * S->it;
-                for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
-                t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = 1.0f; t[46] = S->cur[43]; t[47] = 0.0f;
-            }
-            S->damp = S->damp * damp_new;
-            const float sig = 1.0f / powf(1.0f + expf((-gp.B2) * diff), gp.inv_nu);
-            float sx[6];
-            for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
-            se3_exp_dev(sx, S->dT);
-            mm4(S->dT, S->T, S->T);
-            S->it += 1;
-            // the next launch transforms buf[sel] by dT into buf[1-sel] and that becomes current
-            fill = 1 - S->sel;
-            S->sel = 1 - S->sel;
+    if (threadIdx.x != 0) return;
+    float lin[44];
+    expand44(acc, lin);
+    if (mode == STEP_ADOPT) {
+        adopt_look(S, lin);
+        S->b_first = S->b_cur;
+        solve6(S->cur, S->cur + 36, S->damp, S->xi);
+        se3_exp_dev(S->xi, S->dT);
+    } else if (mode == STEP_LM) {
+        const float err = S->cur[42], new_err = lin[42];
+        const bool accept = new_err < err;
+        if (trace) {
+            float *t = trace + 48 * S->it;
+            for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
+            t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = accept ? 1.0f : 0.0f; t[46] = S->cur[43];
+            t[47] = 0.0f;
         }
-        if (out_T)
-            for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
-        s_next_fill = last ? -1 : fill;  // nothing follows the last step: keep every NN buffer intact
+        S->b_first = S->b_cur;
+        if (accept) {
+            adopt_look(S, lin);
+            S->damp = S->damp / 2.0f;
+            mm4(S->dT, S->T, S->T);
+        } else {
+            discard_look(S);
+            S->damp = S->damp * 2.0f;
+        }
+        S->it += 1;
+        solve6(S->cur, S->cur + 36, S->damp, S->xi);
+        se3_exp_dev(S->xi, S->dT);
+    } else {  // STEP_GRAD_B
+        const float err = S->cur[42], new_err = lin[42];
+        float diff = new_err - err;
+        diff = fminf(fmaxf(diff, -70.0f), 70.0f);
+        const float damp_new = gp.lambda_min + gp.range / (1.0f + expf((-gp.B) * diff));
+        if (trace) {
+            float *t = trace + 48 * S->it;
+            for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
+            t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = 1.0f; t[46] = S->cur[43]; t[47] = 0.0f;
+        }
+        S->b_first = S->b_cur;
+        S->damp = S->damp * damp_new;
+        const float sig = 1.0f / powf(1.0f + expf((-gp.B2) * diff), gp.inv_nu);
+        float sx[6];
+        for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
+        se3_exp_dev(sx, S->dT);
+        mm4(S->dT, S->T, S->T);
+        S->it += 1;
+        discard_look(S);  // the next launch re-derives the cloud from pts[p_cur] with the damped step
     }
-    __syncthreads();
-    if (s_next_fill >= 0) {
-        unsigned long long *dst = (s_next_fill == 0) ? bestA : bestB;
-        for (int i = threadIdx.x; i < max_ns; i += 64) dst[i] = ~0ull;
-    }
+    if (out_T)
+        for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
 }
 
 __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, float damp) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int i = 0; i < 16; ++i) { S->T[i] = init_T[i]; S->dT[i] = init_T[i]; }
+        for (int i = 0; i < 44; ++i) S->cur[i] = 0.0f;
         S->damp = damp;
-        S->sel = 0;  // the first association launch writes buf[0] = init_T . src
-        S->sel_first = 0;
+        S->p_cur = 1;  // the first association writes pts[0]
+        S->b_cur = 2; S->b_look = 0; S->b_spare = 1; S->b_first = 2;
         S->it = 0;
     }
 }
 
-// association launch parameterised by the device-side selector: reads buf[in_sel] (or the user's
-// src for the very first launch), writes buf[out] .
-__global__ __launch_bounds__(KNN_T) void knn1_sel_k(const IcpState *__restrict__ S, int first, const float *__restrict__ user_src,
-                                                    float *__restrict__ bufA, float *__restrict__ bufB,
-                                                    const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
-                                                    const int32_t *__restrict__ d_nt, int nsplit,
-                                                    unsigned long long *__restrict__ bestA,
-                                                    unsigned long long *__restrict__ bestB, int grad_mode_b) {
-    // first launch: in = user src, T = init_T (held in S->dT), out = buf[0]
-    // LM look-ahead / grad pass B: in = buf[sel], T = dT, out = buf[1-sel]
-    // grad pass A (after STEP_GRAD_B flipped sel): in = buf[1-sel], T = dT, out = buf[sel]
-    const int sel = S->sel;
-    const float *in;
-    float *out;
-    unsigned long long *best;
-    if (first) {
-        in = user_src; out = bufA; best = bestA;
-    } else if (grad_mode_b == 2) {  // pass A of gradICP iterations > 0
-        in = sel ? bufA : bufB; out = sel ? bufB : bufA; best = sel ? bestB : bestA;
-    } else {
-        in = sel ? bufB : bufA; out = sel ? bufA : bufB; best = sel ? bestA : bestB;
-    }
-    const int ns = *d_ns, nt = *d_nt;
-    const int tile0 = blockIdx.x * KNN_TILE;
-    if (tile0 >= ns) return;
-    const int chunk = (nt + nsplit - 1) / nsplit;
-    const int j0 = blockIdx.y * chunk;
-    const int j1 = min(nt, j0 + chunk);
-    const float *T = S->dT;
-    float sx[KNN_SPT], sy[KNN_SPT], sz[KNN_SPT], bd[KNN_SPT];
-    int bi[KNN_SPT];
-    bool ok[KNN_SPT];
-#pragma unroll
-    for (int k = 0; k < KNN_SPT; ++k) {
-        const int i = tile0 + k * KNN_T + threadIdx.x;
-        ok[k] = i < ns;
-        f3 p{0.0f, 0.0f, 0.0f};
-        if (ok[k]) {
-            p = xform(T, ld3(in, i));
-            if (blockIdx.y == 0) st3(out, i, p);
-        }
-        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
-        bd[k] = INFINITY;
-        bi[k] = 0;
-    }
-    if (j0 >= j1) return;
-    for (int j = j0; j < j1; ++j) {
-        const float tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
-#pragma unroll
-        for (int k = 0; k < KNN_SPT; ++k) {
-            const float dx = sx[k] - tx, dy = sy[k] - ty, dz = sz[k] - tz;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            if (d < bd[k]) { bd[k] = d; bi[k] = j; }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < KNN_SPT; ++k) {
-        if (!ok[k] || !(bd[k] < INFINITY)) continue;
-        const int i = tile0 + k * KNN_T + threadIdx.x;
-        atomicMin(best + i, ((unsigned long long)fbits(bd[k]) << 32) | (unsigned int)bi[k]);
-    }
-}
-
-// linearise the cloud the association launch above just produced (same selector logic)
-__global__ __launch_bounds__(LIN_T) void linearize_sel_k(const IcpState *__restrict__ S, int first, const float *__restrict__ bufA,
-                                                         const float *__restrict__ bufB, const int32_t *__restrict__ d_ns,
-                                                         const float *__restrict__ tgt, const float *__restrict__ nrm,
-                                                         const unsigned long long *__restrict__ bestA,
-                                                         const unsigned long long *__restrict__ bestB, float thresh,
-                                                         int grad_mode_b, float *__restrict__ partials) {
-    const int sel = S->sel;
-    const float *src;
-    const unsigned long long *best;
-    if (first) { src = bufA; best = bestA; }
-    else if (grad_mode_b == 2) { src = sel ? bufB : bufA; best = sel ? bestB : bestA; }
-    else { src = sel ? bufA : bufB; best = sel ? bestA : bestB; }
-    const int ns = *d_ns;
-    float acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
-        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
-        if (!r.valid) continue;
-        int q = 0;
-#pragma unroll
-        for (int u = 0; u < 6; ++u)
-#pragma unroll
-            for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
-        acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
-        acc[28] += 1.0f;
-    }
-    __shared__ float sm[LIN_T / 64][NACC];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        const float v = wave_sum(acc[k]);
-        if (lane == 0) sm[wid][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        float v = 0.0f;
-#pragma unroll
-        for (int w = 0; w < LIN_T / 64; ++w) v += sm[w][threadIdx.x];
-        partials[blockIdx.x * NACC + threadIdx.x] = v;
-    }
-}
-
-__global__ void copy_best_last_k(const IcpState *__restrict__ S, const unsigned long long *__restrict__ bestA,
-                                 const unsigned long long *__restrict__ bestB, const int32_t *__restrict__ d_ns,
+__global__ void copy_best_last_k(const IcpState *__restrict__ S, LoopBufs B, const int32_t *__restrict__ d_ns,
                                  unsigned long long *__restrict__ out) {
-    const unsigned long long *src = S->sel_first ? bestB : bestA;
+    const unsigned long long *src = B.best[S->b_first];
     const int ns = *d_ns;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) out[i] = src[i];
 }
 
-static inline int knn_nsplit(int max_ns, int max_nt) {
-    const int tiles = cdiv(max_ns, KNN_TILE);
+// ------------------------------------------------------------------ launch geometry
+static inline int knn_nsplit_brute(int max_ns, int max_nt) {
+    const int tiles = cdiv(max_ns, KNN_T);
     int ns = cdiv(2048, tiles);
     const int cap = cdiv(max_nt, 64);
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     if (ns > 4096) ns = 4096;
+    return ns;
+}
+// pruned search: aim at ~4 waves per SIMD over the chip, but never less than 8 chunks per range
+static inline int knn_nsplit_box(int max_ns, int max_nt) {
+    const int waves = cdiv(max_ns, 64);
+    int ns = cdiv(4096, waves);
+    const int cap = cdiv(cdiv(max_nt, CHUNK), 8);
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    if (ns > 64) ns = 64;
     return ns;
 }
 static inline int lin_blocks(int max_ns) {
@@ -570,6 +620,7 @@ static inline int lin_blocks(int max_ns) {
     if (nb < 1) nb = 1;
     return nb;
 }
+static inline size_t boxes_bytes(int max_nt) { return align_up((size_t)cdiv(max_nt > 0 ? max_nt : 1, CHUNK) * 6 * 4, 256); }
 
 // ------------------------------------------------------------------ optional per-kernel timing
 // bench.py asks for the average duration of the two hot kernels of the loop, measured with HIP events
@@ -597,23 +648,27 @@ static inline void prof_mark(int tag, int which, hipStream_t st) {
 
 struct IcpWs {
     IcpState *S;
-    float *bufA, *bufB;
-    unsigned long long *bestA, *bestB;
+    LoopBufs B;
     float *partials;
+    float *boxes;
 };
-static inline size_t icp_ws_layout(int max_ns, void *ws, IcpWs *out) {
+static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t oS = take(sizeof(IcpState));
-    const size_t oA = take((size_t)max_ns * 12), oB = take((size_t)max_ns * 12);
-    const size_t obA = take((size_t)max_ns * 8), obB = take((size_t)max_ns * 8);
-    const size_t oP = take((size_t)LIN_MAXB * NACC * 4);
+    const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
+    const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8), oB2 = take((size_t)max_ns * 8);
+    const size_t oPart = take((size_t)LIN_MAXB * NACC * 4);
+    const size_t oBox = take(boxes_bytes(max_nt));
     if (ws && out) {
         char *p = (char *)ws;
         out->S = (IcpState *)(p + oS);
-        out->bufA = (float *)(p + oA); out->bufB = (float *)(p + oB);
-        out->bestA = (unsigned long long *)(p + obA); out->bestB = (unsigned long long *)(p + obB);
-        out->partials = (float *)(p + oP);
+        out->B.pts[0] = (float *)(p + oP0); out->B.pts[1] = (float *)(p + oP1);
+        out->B.best[0] = (unsigned long long *)(p + oB0);
+        out->B.best[1] = (unsigned long long *)(p + oB1);
+        out->B.best[2] = (unsigned long long *)(p + oB2);
+        out->partials = (float *)(p + oPart);
+        out->boxes = (float *)(p + oBox);
     }
     return off;
 }
@@ -624,63 +679,59 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
                    hipStream_t st, const char *name) {
     GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && init_T && out_T, "%s: NULL argument", name);
     GS_REQUIRE(max_ns > 0 && max_nt > 0 && numiters >= 0, "%s: bad sizes max_ns=%d max_nt=%d numiters=%d", name, max_ns, max_nt, numiters);
-    if (!ws || ws_bytes < icp_ws_layout(max_ns, nullptr, nullptr)) {
-        set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, icp_ws_layout(max_ns, nullptr, nullptr));
+    if (!ws || ws_bytes < icp_ws_layout(max_ns, max_nt, nullptr, nullptr)) {
+        set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, icp_ws_layout(max_ns, max_nt, nullptr, nullptr));
         return GS_ERR_WORKSPACE_TOO_SMALL;
     }
-    IcpWs w;
-    icp_ws_layout(max_ns, ws, &w);
-    const int nsplit = knn_nsplit(max_ns, max_nt);
-    const dim3 kgrid(cdiv(max_ns, KNN_TILE), nsplit);
-    const int lb = lin_blocks(max_ns);
-    const int fb = min(cdiv(max_ns, 256), 256);
-
-    hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
-    hipLaunchKernelGGL(fill_u64_k, dim3(fb), dim3(256), 0, st, w.bestA, max_ns, ~0ull);
-    GS_LAUNCH_CHECK(name);
     if (numiters == 0) {
         GS_HIP(hipMemcpyAsync(out_T, init_T, 64, hipMemcpyDeviceToDevice, st), name);
         return GS_OK;
     }
-    auto assoc = [&](int first, int gm) {
+    IcpWs w;
+    icp_ws_layout(max_ns, max_nt, ws, &w);
+    const int nsplit = knn_nsplit_box(max_ns, max_nt);
+    const dim3 kgrid(cdiv(max_ns, KNN_T), nsplit);
+    const int lb = lin_blocks(max_ns);
+    const int fb = min(cdiv(max_ns, 256), 256);
+
+    hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
+    hipLaunchKernelGGL(fill_u64_k, dim3(fb), dim3(256), 0, st, w.B.best[0], max_ns, KEY_NONE);
+    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, CHUNK)), dim3(64), 0, st, tgt, d_nt, w.boxes);
+    GS_LAUNCH_CHECK(name);
+    auto assoc = [&](int first) {
         prof_mark(0, 0, st);
-        hipLaunchKernelGGL(knn1_sel_k, kgrid, dim3(KNN_T), 0, st, w.S, first, src, w.bufA, w.bufB, d_ns, tgt, d_nt, nsplit,
-                           w.bestA, w.bestB, gm);
+        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_T), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt, nsplit);
         prof_mark(0, 1, st);
         prof_mark(1, 0, st);
-        hipLaunchKernelGGL(linearize_sel_k, dim3(lb), dim3(LIN_T), 0, st, w.S, first, w.bufA, w.bufB, d_ns, tgt, nrm,
-                           w.bestA, w.bestB, thresh, gm, w.partials);
+        hipLaunchKernelGGL(linearize_loop_k, dim3(lb), dim3(LIN_T), 0, st, w.S, w.B, d_ns, max_ns, tgt, nrm, thresh,
+                           w.partials);
         prof_mark(1, 1, st);
     };
-    auto step = [&](int mode, int last) {
-        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(64), 0, st, w.S, w.partials, lb, mode, last, gp, trace, w.bestA,
-                           w.bestB, max_ns, out_T);
+    auto step = [&](int mode) {
+        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(256), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T);
     };
+    assoc(1);
+    step(STEP_ADOPT);
     if (!grad) {
         // numiters + 1 associations instead of the reference's 2 x numiters: an accepted look-ahead
         // IS the next iteration's first linearisation, a rejected one leaves it unchanged.
-        assoc(1, 0);
-        step(STEP_INIT, 0);
         for (int it = 0; it < numiters; ++it) {
-            assoc(0, 0);
-            step(STEP_LM, it + 1 == numiters);
+            assoc(0);
+            step(STEP_LM);
         }
     } else {
-        assoc(1, 0);
-        step(STEP_GRAD_A, 0);
         for (int it = 0; it < numiters; ++it) {
-            assoc(0, 1);                              // look-ahead: buf[sel] . dT -> buf[1-sel]
-            step(STEP_GRAD_B, it + 1 == numiters);    // dT = exp(sigma xi); flips sel
+            assoc(0);            // look-ahead: pts[p_cur] . exp(xi)
+            step(STEP_GRAD_B);   // dT = exp(sigma xi); look-ahead discarded
             if (it + 1 < numiters) {
-                assoc(0, 2);                          // current cloud: buf[1-sel] . dT -> buf[sel]
-                step(STEP_GRAD_A, 0);
+                assoc(0);        // new current cloud: pts[p_cur] . exp(sigma xi)
+                step(STEP_ADOPT);
             }
         }
     }
     GS_LAUNCH_CHECK(name);
     if (best_last) {
-        hipLaunchKernelGGL(copy_best_last_k, dim3(fb), dim3(256), 0, st, w.S, w.bestA, w.bestB, d_ns,
-                           (unsigned long long *)best_last);
+        hipLaunchKernelGGL(copy_best_last_k, dim3(fb), dim3(256), 0, st, w.S, w.B, d_ns, (unsigned long long *)best_last);
         GS_LAUNCH_CHECK(name);
     }
     return GS_OK;
@@ -716,19 +767,43 @@ int gs_profile_read(int tag, long *launches, double *total_ms) {
     return GS_OK;
 }
 
+size_t gs_knn1_ws_bytes(int max_nt) { return boxes_bytes(max_nt); }
+
 int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const int32_t *d_nt, int max_nt,
-            uint64_t *best, gs_stream_t stream) {
+            uint64_t *best, void *ws, size_t ws_bytes, gs_stream_t stream) {
     GS_REQUIRE(src && d_ns && tgt && d_nt && best, "gs_knn1: NULL argument");
     GS_REQUIRE(max_ns >= 0 && max_nt >= 0, "gs_knn1: negative size");
     if (max_ns == 0) return GS_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fill_u64_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, st, (unsigned long long *)best, max_ns, ~0ull);
+    hipLaunchKernelGGL(fill_u64_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, st, (unsigned long long *)best, max_ns, KEY_NONE);
     GS_LAUNCH_CHECK("gs_knn1/fill");
     if (max_nt == 0) return GS_OK;
-    const int nsplit = knn_nsplit(max_ns, max_nt);
-    hipLaunchKernelGGL(knn1_k, dim3(cdiv(max_ns, KNN_TILE), nsplit), dim3(KNN_T), 0, st, src, d_ns, (const float *)nullptr,
-                       (float *)nullptr, tgt, d_nt, nsplit, (unsigned long long *)best);
+    if (!ws || ws_bytes < boxes_bytes(max_nt)) {
+        set_error("gs_knn1: workspace too small (%zu < %zu)", ws_bytes, boxes_bytes(max_nt));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, CHUNK)), dim3(64), 0, st, tgt, d_nt, (float *)ws);
+    GS_LAUNCH_CHECK("gs_knn1/boxes");
+    const int nsplit = knn_nsplit_box(max_ns, max_nt);
+    hipLaunchKernelGGL(knn1_box_k, dim3(cdiv(max_ns, KNN_T), nsplit), dim3(KNN_T), 0, st, src, d_ns, tgt, (const float *)ws,
+                       d_nt, nsplit, (unsigned long long *)best);
     GS_LAUNCH_CHECK("gs_knn1");
+    return GS_OK;
+}
+
+int gs_knn1_bruteforce(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const int32_t *d_nt,
+                       int max_nt, uint64_t *best, gs_stream_t stream) {
+    GS_REQUIRE(src && d_ns && tgt && d_nt && best, "gs_knn1_bruteforce: NULL argument");
+    GS_REQUIRE(max_ns >= 0 && max_nt >= 0, "gs_knn1_bruteforce: negative size");
+    if (max_ns == 0) return GS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_u64_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, st, (unsigned long long *)best, max_ns, KEY_NONE);
+    GS_LAUNCH_CHECK("gs_knn1_bruteforce/fill");
+    if (max_nt == 0) return GS_OK;
+    const int nsplit = knn_nsplit_brute(max_ns, max_nt);
+    hipLaunchKernelGGL(knn1_brute_k, dim3(cdiv(max_ns, KNN_T), nsplit), dim3(KNN_T), 0, st, src, d_ns, tgt, d_nt, nsplit,
+                       (unsigned long long *)best);
+    GS_LAUNCH_CHECK("gs_knn1_bruteforce");
     return GS_OK;
 }
 
@@ -753,15 +828,11 @@ int gs_icp_linearize(const float *src, const int32_t *d_ns, int max_ns, const fl
         return GS_ERR_WORKSPACE_TOO_SMALL;
     }
     hipStream_t st = (hipStream_t)stream;
-    // large clouds: several points per thread, grid capped so the partial tree stays two-level
-    int nb = cdiv(max_ns, LIN_T * 4);
-    if (nb < lin_blocks(max_ns) && max_ns <= LIN_T * LIN_MAXB) nb = lin_blocks(max_ns);
-    if (nb > LIN_MAXB) nb = LIN_MAXB;
-    if (nb < 1) nb = 1;
+    const int nb = lin_blocks(max_ns);  // capped at LIN_MAXB: large clouds grid-stride
     hipLaunchKernelGGL(linearize_k, dim3(nb), dim3(LIN_T), 0, st, src, d_ns, tgt, tgt_normals,
                        (const unsigned long long *)best, dist_thresh, (float *)ws);
     GS_LAUNCH_CHECK("gs_icp_linearize");
-    hipLaunchKernelGGL(finalize44_k, dim3(1), dim3(64), 0, st, (const float *)ws, nb, out44);
+    hipLaunchKernelGGL(finalize44_k, dim3(1), dim3(1024), 0, st, (const float *)ws, nb, out44);
     GS_LAUNCH_CHECK("gs_icp_linearize/finalize");
     return GS_OK;
 }
@@ -795,7 +866,9 @@ int gs_transform_points(const float *pts, const int32_t *d_n, int max_n, const f
     return GS_OK;
 }
 
-size_t gs_icp_ws_bytes(int max_ns) { return icp_ws_layout(max_ns > 0 ? max_ns : 1, nullptr, nullptr); }
+size_t gs_icp_ws_bytes(int max_ns, int max_nt) {
+    return icp_ws_layout(max_ns > 0 ? max_ns : 1, max_nt > 0 ? max_nt : 1, nullptr, nullptr);
+}
 
 int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
                           const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp,
@@ -814,8 +887,7 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
     return icp_run(true, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, damp, dist_thresh,
                    GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max), B, B2,
                               (float)(1.0 / (double)nu)},
-                   out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream,
-                   "gs_icp_point_to_plane_grad");
+                   out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream, "gs_icp_point_to_plane_grad");
 }
 
 }  // extern "C"

@@ -223,15 +223,21 @@ def table_ds_mask(rows: torch.Tensor, ds: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------- K / J
-def knn1_raw(src, tgt, ns_dev=None, nt_dev=None) -> torch.Tensor:
-    """src (Ns,3), tgt (Nt,3) -> packed best (Ns,) int64 = dist_bits << 32 | idx."""
+def knn1_raw(src, tgt, ns_dev=None, nt_dev=None, brute_force: bool = False) -> torch.Tensor:
+    """src (Ns,3), tgt (Nt,3) -> packed best (Ns,) int64 = dist_bits << 32 | idx.  The default kernel
+    prunes target chunks with an exact AABB bound; brute_force=True evaluates every pair (verifier)."""
     require_hip(src, tgt, op="knn1")
     src, tgt = _f32c(src), _f32c(tgt)
     dev = src.device
     ns_dev = dev_int(src.shape[0], dev) if ns_dev is None else ns_dev
     nt_dev = dev_int(tgt.shape[0], dev) if nt_dev is None else nt_dev
     best = torch.empty(src.shape[0], dtype=torch.int64, device=dev)
-    call("gs_knn1", ptr(src), ptr(ns_dev), src.shape[0], ptr(tgt), ptr(nt_dev), tgt.shape[0], ptr(best), stream())
+    if brute_force:
+        call("gs_knn1_bruteforce", ptr(src), ptr(ns_dev), src.shape[0], ptr(tgt), ptr(nt_dev), tgt.shape[0], ptr(best), stream())
+    else:
+        ws = workspace(ws_bytes("gs_knn1_ws_bytes", tgt.shape[0]), dev, "knn")
+        call("gs_knn1", ptr(src), ptr(ns_dev), src.shape[0], ptr(tgt), ptr(nt_dev), tgt.shape[0], ptr(best), ptr(ws),
+             ws.numel(), stream())
     return best
 
 
@@ -355,7 +361,7 @@ def icp_device_loop(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_par
     T = torch.empty((4, 4), dtype=torch.float32, device=dev)
     best = torch.empty(ns, dtype=torch.int64, device=dev) if want_best else None
     trace = torch.zeros((max(numiters, 1), 48), dtype=torch.float32, device=dev) if want_trace else None
-    ws = workspace(ws_bytes("gs_icp_ws_bytes", ns), dev, "icp")
+    ws = workspace(ws_bytes("gs_icp_ws_bytes", ns, nt), dev, "icp")
     d_ns, d_nt = dev_int(ns, dev), dev_int(nt, dev)
     if grad_params is None:
         call("gs_icp_point_to_plane", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),

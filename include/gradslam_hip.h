@@ -121,9 +121,15 @@ int gs_table_ds_mask(const int64_t *rows, int64_t n_rows, int ds, uint8_t *mask,
  * for each source point the squared L2 distance ((dx^2+dy^2)+dz^2, fp32, no FMA) to, and index of,
  * the nearest target point; the lowest index wins ties.  ns / nt are read from device memory
  * (d_ns, d_nt) so the call needs no host round trip; max_ns / max_nt bound the launch.
- * best: packed (dist_bits << 32 | idx) per source point, the form the J kernels consume. */
+ * best: packed (dist_bits << 32 | idx) per source point, the form the J kernels consume.
+ * gs_knn1 prunes target chunks by an exact fp32 AABB lower bound (same result, far fewer pairs);
+ * gs_knn1_bruteforce evaluates every pair (the verifier). */
+size_t gs_knn1_ws_bytes(int max_nt);
 int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
-            const int32_t *d_nt, int max_nt, uint64_t *best, gs_stream_t stream);
+            const int32_t *d_nt, int max_nt, uint64_t *best, void *ws, size_t ws_bytes,
+            gs_stream_t stream);
+int gs_knn1_bruteforce(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                       const int32_t *d_nt, int max_nt, uint64_t *best, gs_stream_t stream);
 /* unpack to the reference's output types: dist2 fp32 (ns), idx int64 (ns) */
 int gs_knn1_unpack(const uint64_t *best, const int32_t *d_ns, int max_ns, float *dist2,
                    int64_t *idx, gs_stream_t stream);
@@ -164,7 +170,7 @@ int gs_transform_points(const float *pts, const int32_t *d_n, int max_n, const f
  * on the device.  src (ns,3), tgt/normals (nt,3), init_T (device 4x4).  Outputs: T (device 4x4),
  * optional best_last (packed NN of the last iteration's first solve) and optional trace
  * (numiters x 48 floats: H36|g6|err|new_err|damp|accept|cnt|pad).  dist_thresh < 0 == None. */
-size_t gs_icp_ws_bytes(int max_ns);
+size_t gs_icp_ws_bytes(int max_ns, int max_nt);
 int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
                           const float *tgt_normals, const int32_t *d_nt, int max_nt,
                           const float *init_T, int numiters, float damp, float dist_thresh,

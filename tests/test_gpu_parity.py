@@ -76,26 +76,36 @@ def test_maps_no_poses_and_channels_first(gs, golden):
     assert torch.equal(rcf.normal_map.permute(0, 1, 3, 4, 2), rcl.normal_map)
 
 
-def test_maps_backward_vs_oracle(gs, golden):
+def _maps_grads(gs, depth0, K0, P0, w):
     from oracle import maps
 
-    g = golden("ref_slam_c1")
-    torch.manual_seed(1)
-    w = [torch.randn(1, 2, 64, 64, 3) for _ in range(4)]
     grads = []
     for dev in ("cpu", DEV):
-        depth, K, P = (t(g[k]).to(dev).clone().requires_grad_(True) for k in ("depths", "intrinsics", "poses"))
-        if dev == "cpu":
-            outs = maps.all_maps(depth, K, P)
-        else:
-            outs = gs.ops.vertex_normal_maps(depth, K, P)
-        loss = sum((o * wi.to(dev)).sum() for o, wi in zip(outs, w))
-        loss.backward()
+        depth, K, P = (x.to(dev).clone().requires_grad_(True) for x in (depth0, K0, P0))
+        outs = maps.all_maps(depth, K, P) if dev == "cpu" else gs.ops.vertex_normal_maps(depth, K, P)
+        sum((o * wi.to(dev)).sum() for o, wi in zip(outs, w)).backward()
         grads.append([x.grad.cpu() for x in (depth, K, P)])
-    # Pixels whose two forward neighbours are invalid get dh == dv: the cross product is a rounding
-    # residue, the "normal" is garbage and its gradient is O(1/residue) noise in the reference too.
-    # Exclude those stencils (dilated by one pixel), compare everything else tightly.
+    return grads
+
+
+def test_maps_backward_vs_oracle(gs, golden):
+    from gradslam_amd.synthetic import make_sequence
+    from oracle import maps
+
+    torch.manual_seed(1)
+    w = [torch.randn(1, 2, 64, 64, 3) for _ in range(4)]
+    # (a) hole-free depth: every gradient (depth, intrinsics, poses) tight
+    _, dclean, K, P = make_sequence(1, 2, 64, 64, seed=0, dropout=0.0, band=0)
+    got, ref = _maps_grads(gs, dclean, K, P, w)[::-1]
+    for name, a, b in zip(("depth", "K", "poses"), got, ref):
+        print("clean", name, rel_err(a, b))
+        assert rel_err(a, b) < 2e-4, name
+    # (b) depth with holes.  Pixels whose two forward neighbours are invalid get dh == dv: the cross
+    # product is a rounding residue, the "normal" is garbage and its gradient is O(1/residue) noise in the
+    # reference too.  Exclude those stencils (dilated by one pixel), compare everything else tightly.
+    g = golden("ref_slam_c1")
     depth = t(g["depths"])
+    got, ref = _maps_grads(gs, depth, t(g["intrinsics"]), t(g["poses"]), w)[::-1]
     V = maps.vertex_map(depth, t(g["intrinsics"]))
     dh, dv = torch.zeros_like(V), torch.zeros_like(V)
     dh[..., :-1, :] = V[..., 1:, :] - V[..., :-1, :]
@@ -104,16 +114,10 @@ def test_maps_backward_vs_oracle(gs, golden):
     cr = torch.cross(dh, dv, dim=-1).norm(dim=-1)
     degenerate = (cr < 1e-3 * dh.norm(dim=-1) * dv.norm(dim=-1)).float()
     bad = torch.nn.functional.max_pool2d(degenerate.view(-1, 1, 64, 64), 3, 1, 1).view(1, 2, 64, 64, 1) > 0
-    print("degenerate-stencil pixels excluded:", bad.float().mean().item())
-    gd, od = grads[1][0], grads[0][0]
-    scale = od[~bad].abs().max()
-    err_d = ((gd - od)[~bad].abs().max() / scale).item()
-    print("depth grad rel err on well-posed pixels", err_d)
+    err_d = ((got[0] - ref[0])[~bad].abs().max() / ref[0][~bad].abs().max()).item()
+    print("holes: degenerate-stencil pixels excluded", bad.float().mean().item(), "depth grad rel err elsewhere", err_d)
     assert err_d < 2e-4 and bad.float().mean() < 0.25
-    for name, a, b in zip(("K", "poses"), grads[1][1:], grads[0][1:]):
-        print(name, rel_err(a, b))
-    # K and pose gradients sum over all pixels including the garbage ones -> looser
-    assert rel_err(grads[1][2], grads[0][2]) < 1e-2 and rel_err(grads[1][1], grads[0][1]) < 5e-2
+    assert rel_err(got[2], ref[2]) < 1e-2  # pose gradient: sums the garbage pixels too
 
 
 # ------------------------------------------------------------------ K
@@ -129,6 +133,26 @@ def test_knn_bit_exact_random(gs, ns, nt):
     assert torch.equal(idx.cpu(), oidx) and torch.equal(d2.cpu(), od2)
     # independent fp64 bound on the distances (the oracle's own contract is parity-unpinned)
     assert torch.allclose(d2.cpu().double(), knn1_f64(src, tgt), rtol=1e-5, atol=1e-10)
+
+
+@pytest.mark.parametrize("kind", ["random", "sorted", "duplicates", "far"])
+def test_knn_pruned_equals_bruteforce(gs, kind):
+    """The AABB-pruned search must return the brute-force scan's bits on any input, including ones where
+    pruning cannot help (unordered clouds) and ones full of ties."""
+    torch.manual_seed(11)
+    ns, nt = 7000, 9000
+    src, tgt = torch.randn(ns, 3, device=DEV), torch.randn(nt, 3, device=DEV)
+    if kind == "sorted":
+        tgt = tgt[tgt[:, 0].argsort()].contiguous()
+        src = src[src[:, 0].argsort()].contiguous()
+    elif kind == "duplicates":
+        tgt = (tgt * 4).round() / 4      # lattice: many exact ties
+        src = (src * 4).round() / 4
+    elif kind == "far":
+        src = src + 50.0
+    a = gs.ops.knn1_raw(src, tgt)
+    b = gs.ops.knn1_raw(src, tgt, brute_force=True)
+    assert torch.equal(a, b)
 
 
 def test_knn_image_order_clouds(gs, golden):
