@@ -28,7 +28,11 @@
 
 namespace gs {
 
-constexpr int KNN_T = 256;      // threads per block (4 waves, one 64-point source tile each)
+constexpr int KNN_T = 256;      // brute force: threads per block
+constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving the same 64 source points
+constexpr int KNN_BT = KNN_NW * 64;
+constexpr int KNN_ROUND = 2048; // chunks tested per round (= capacity of the LDS candidate list)
+constexpr int KNN_COARSE = 2048;// target points sampled by the seed pass when no seed is given
 constexpr int CHUNK = 64;       // target points per AABB chunk
 constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
@@ -90,28 +94,86 @@ __global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt,
     }
 }
 
-// Search chunks [c0, c1) for the lane's point s.  (bd, bi) carry the running lexicographic best.
-__device__ __forceinline__ void box_search(const f3 s, const bool ok, const float *__restrict__ tgt,
-                                           const float *__restrict__ boxes, int nt, int c0, int c1, float &bd, int &bi) {
-    for (int c = c0; c < c1; ++c) {
-        const float *b = boxes + 6 * c;  // wave-uniform -> scalar loads
-        // per-axis distance to the box, then the SAME accumulation order as dist2 (monotone rounding
-        // => lower bound holds exactly in fp32)
-        const float ex = fmaxf(fmaxf(b[0] - s.x, s.x - b[3]), 0.0f);
-        const float ey = fmaxf(fmaxf(b[1] - s.y, s.y - b[4]), 0.0f);
-        const float ez = fmaxf(fmaxf(b[2] - s.z, s.z - b[5]), 0.0f);
-        const float lb = (ex * ex + ey * ey) + ez * ez;
-        if (!__any(ok && lb <= bd)) continue;  // every lane: bound strictly above its best -> skip
-        const int j0 = c * CHUNK, j1 = min(nt, j0 + CHUNK);
-        for (int j = j0; j < j1; ++j) {
-            const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
-            if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }  // (distance, index) lexicographic
-        }
-    }
+// Cooperative exact search of one 64-point source tile by the KNN_NW waves of a block.  Every wave
+// holds the same 64 source points (lane = point); the waves share the work over TARGET chunks:
+//   seed   : one real candidate per lane (given index, or the best of a strided sample of the target)
+//   round  : waves test disjoint chunk boxes against the lanes' current best and append the chunks that
+//            may still matter to an LDS list; then waves scan disjoint list entries; then the lanes' bests
+//            are merged across waves through LDS, which tightens the bound for the next round.
+// The critical path is (boxes + surviving points) / KNN_NW instead of a whole target range per wave.
+struct KnnShared {
+    unsigned long long key[KNN_NW][64];
+    int list[KNN_ROUND];
+    int cnt;
+};
+
+__device__ __forceinline__ void knn_merge(KnnShared &sh, bool ok, float &bd, int &bi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sh.key[wave][lane] = (ok && bd < INFINITY) ? pack_key(bd, bi) : KEY_NONE;
+    __syncthreads();
+    unsigned long long m = sh.key[0][lane];
+#pragma unroll
+    for (int w = 1; w < KNN_NW; ++w) m = min(m, sh.key[w][lane]);
+    __syncthreads();
+    if (m != KEY_NONE) { bd = bitsf((uint32_t)(m >> 32)); bi = (int)(uint32_t)(m & 0xffffffffu); }
 }
 
-// Device-resident loop state.  Point clouds ping-pong between pts[0..1]; nearest-neighbour buffers
-// rotate through best[0..2] (current / in flight / being cleared).
+// returns the packed key of lane's point (KEY_NONE when there is no target)
+__device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s, const bool ok, const int seed_j,
+                                                       const float *__restrict__ tgt, const float *__restrict__ boxes,
+                                                       const int nt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float bd = INFINITY;
+    int bi = 0;
+    if (seed_j >= 0) {
+        if (ok) {
+            const f3 q = ld3(tgt, seed_j);
+            bd = dist2(s, q.x, q.y, q.z);
+            bi = seed_j;
+        }
+    } else {
+        // seed pass: strided sample of the target, shared over the waves (wave-uniform loads)
+        const int M = min(nt, KNN_COARSE);
+        for (int k = wave; k < M; k += KNN_NW) {
+            const int j = (int)(((long long)k * nt) / M);
+            const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
+            if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }
+        }
+        knn_merge(sh, ok, bd, bi);
+    }
+    const int nchunks = (nt + CHUNK - 1) / CHUNK;
+    for (int r0 = 0; r0 < nchunks; r0 += KNN_ROUND) {
+        if (threadIdx.x == 0) sh.cnt = 0;
+        __syncthreads();
+        const int r1 = min(nchunks, r0 + KNN_ROUND);
+        for (int c = r0 + wave; c < r1; c += KNN_NW) {
+            const float *b = boxes + 6 * c;  // wave-uniform -> scalar loads
+            // per-axis distance to the box, then the SAME accumulation order as dist2 (monotone rounding
+            // => the lower bound holds exactly in fp32)
+            const float ex = fmaxf(fmaxf(b[0] - s.x, s.x - b[3]), 0.0f);
+            const float ey = fmaxf(fmaxf(b[1] - s.y, s.y - b[4]), 0.0f);
+            const float ez = fmaxf(fmaxf(b[2] - s.z, s.z - b[5]), 0.0f);
+            const float lb = (ex * ex + ey * ey) + ez * ez;
+            // keep the chunk unless EVERY lane's bound is strictly above its best
+            if (__any(ok && lb <= bd) && lane == 0) sh.list[atomicAdd(&sh.cnt, 1)] = c;
+        }
+        __syncthreads();
+        const int n = sh.cnt;
+        for (int k = wave; k < n; k += KNN_NW) {
+            const int c = sh.list[k];
+            const int j0 = c * CHUNK, j1 = min(nt, j0 + CHUNK);
+            for (int j = j0; j < j1; ++j) {
+                const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
+                if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }  // (distance, index) lexicographic
+            }
+        }
+        knn_merge(sh, ok, bd, bi);
+    }
+    return (ok && bd < INFINITY) ? pack_key(bd, bi) : KEY_NONE;
+}
+
+// Device-resident loop state.  Point clouds ping-pong between pts[0..1] and nearest-neighbour arrays
+// between best[0..1]; `p_cur` / `b_cur` say which one holds the current cloud.
 struct IcpState {
     float T[16];    // accumulated transform
     float dT[16];   // step the next association launch applies
@@ -119,93 +181,73 @@ struct IcpState {
     float xi[6];
     float damp;
     int p_cur;      // pts[p_cur] = current cloud; the association writes pts[1 - p_cur]
-    int b_cur;      // best[b_cur] = NN of the current cloud
-    int b_look;     // best[b_look]: written by the association in flight (pre-cleared)
-    int b_spare;    // best[b_spare]: cleared by the linearise launch in flight
+    int b_cur;      // best[b_cur] = NN of the current cloud; the association writes best[1 - b_cur]
     int b_first;    // NN buffer of the cloud the last iteration's first solve used
     int it;
 };
 
 struct LoopBufs {
     float *pts[2];
-    unsigned long long *best[3];
+    unsigned long long *best[2];
 };
 
 // Association launch of the loops: in = (first ? user source : pts[p_cur]) transformed by S->dT,
-// out = pts[1 - p_cur], NN -> best[b_look].  Seeds: the current cloud's NN (same source index) when
-// there is one, else the target at the same relative index.
-__global__ __launch_bounds__(KNN_T) void knn1_loop_k(const IcpState *__restrict__ S, int first,
-                                                     const float *__restrict__ user_src, LoopBufs B,
-                                                     const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
-                                                     const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
-                                                     int nsplit) {
+// out = pts[1 - p_cur], NN -> best[1 - b_cur].  Seed: the current cloud's NN of the same source index
+// when there is one, else the sampled seed pass.
+__global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S, int first,
+                                                      const float *__restrict__ user_src, LoopBufs B,
+                                                      const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                                                      const float *__restrict__ boxes, const int32_t *__restrict__ d_nt) {
+    __shared__ KnnShared sh;
     const int ns = *d_ns, nt = *d_nt;
-    const int wave = threadIdx.x >> 6;
-    const int tile0 = (blockIdx.x * (KNN_T / 64) + wave) * 64;
-    if (tile0 >= ns || nt <= 0) return;
-    const int p_cur = S->p_cur;
+    const int tile0 = blockIdx.x * 64;
+    if (tile0 >= ns) return;
+    const int p_cur = S->p_cur, b_cur = S->b_cur;
     const float *in = first ? user_src : B.pts[p_cur];
     float *out = B.pts[1 - p_cur];
-    unsigned long long *best = B.best[S->b_look];
-    const unsigned long long *seed = first ? nullptr : B.best[S->b_cur];
-    const int i = tile0 + (threadIdx.x & 63);
+    unsigned long long *best = B.best[1 - b_cur];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = tile0 + lane;
     const bool ok = i < ns;
     f3 s{0.0f, 0.0f, 0.0f};
     if (ok) {
         s = xform(S->dT, ld3(in, i));
-        if (blockIdx.y == 0) st3(out, i, s);
+        if (wave == 0) st3(out, i, s);
     }
-    // seed with one real candidate
-    int sj = 0;
-    if (ok) {
-        if (seed) {
-            const unsigned long long k = seed[i];
-            sj = (k == KEY_NONE) ? 0 : (int)(uint32_t)(k & 0xffffffffu);
-        } else {
-            sj = (int)(((long long)i * nt) / ns);
+    if (nt <= 0) {
+        if (ok && wave == 0) best[i] = KEY_NONE;
+        return;
+    }
+    int sj = -1;
+    if (!first) {
+        sj = 0;
+        if (ok) {
+            const unsigned long long k = B.best[b_cur][i];
+            sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
         }
-        sj = min(max(sj, 0), nt - 1);
     }
-    float bd = INFINITY;
-    int bi = 0;
-    if (ok) {
-        const f3 q = ld3(tgt, sj);
-        bd = dist2(s, q.x, q.y, q.z);
-        bi = sj;
-    }
-    const int nchunks = (nt + CHUNK - 1) / CHUNK;
-    const int per = (nchunks + nsplit - 1) / nsplit;
-    const int c0 = blockIdx.y * per, c1 = min(nchunks, c0 + per);
-    box_search(s, ok, tgt, boxes, nt, c0, c1, bd, bi);
-    // range 0 always posts (it carries the seed candidate); the others only if they beat the seed
-    if (ok && (blockIdx.y == 0 || bi != sj)) atomicMin(best + i, pack_key(bd, bi));
+    const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, boxes, nt);
+    if (ok && wave == 0) best[i] = key;
 }
 
-// Stand-alone pruned search (gs_knn1): no transform, seed = same relative index.
-__global__ __launch_bounds__(KNN_T) void knn1_box_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
-                                                    const float *__restrict__ tgt, const float *__restrict__ boxes,
-                                                    const int32_t *__restrict__ d_nt, int nsplit,
-                                                    unsigned long long *__restrict__ best) {
+// Stand-alone pruned search (gs_knn1): no transform, sampled seed pass.
+__global__ __launch_bounds__(KNN_BT) void knn1_box_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
+                                                     const float *__restrict__ tgt, const float *__restrict__ boxes,
+                                                     const int32_t *__restrict__ d_nt, unsigned long long *__restrict__ best) {
+    __shared__ KnnShared sh;
     const int ns = *d_ns, nt = *d_nt;
-    const int wave = threadIdx.x >> 6;
-    const int tile0 = (blockIdx.x * (KNN_T / 64) + wave) * 64;
-    if (tile0 >= ns || nt <= 0) return;
-    const int i = tile0 + (threadIdx.x & 63);
+    const int tile0 = blockIdx.x * 64;
+    if (tile0 >= ns) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = tile0 + lane;
     const bool ok = i < ns;
     const f3 s = ok ? ld3(src, i) : f3{0.0f, 0.0f, 0.0f};
-    float bd = INFINITY;
-    int bi = 0, sj = 0;
-    if (ok) {
-        sj = min(max((int)(((long long)i * nt) / ns), 0), nt - 1);
-        const f3 q = ld3(tgt, sj);
-        bd = dist2(s, q.x, q.y, q.z);
-        bi = sj;
+    if (nt <= 0) {
+        if (ok && wave == 0) best[i] = KEY_NONE;
+        return;
     }
-    const int nchunks = (nt + CHUNK - 1) / CHUNK;
-    const int per = (nchunks + nsplit - 1) / nsplit;
-    const int c0 = blockIdx.y * per, c1 = min(nchunks, c0 + per);
-    box_search(s, ok, tgt, boxes, nt, c0, c1, bd, bi);
-    if (ok && (blockIdx.y == 0 || bi != sj)) atomicMin(best + i, pack_key(bd, bi));
+    const unsigned long long key = knn_tile(sh, s, ok, -1, tgt, boxes, nt);
+    if (ok && wave == 0) best[i] = key;
 }
 
 __global__ void knn_unpack_k(const unsigned long long *__restrict__ best, const int32_t *__restrict__ d_ns,
@@ -296,21 +338,18 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
     block_reduce_store(acc, partials);
 }
 
-// linearise the cloud the association launch just produced (pts[1-p_cur], best[b_look]) and clear
-// best[b_spare] for the launch after next
+// linearise the cloud the association launch just produced (pts[1-p_cur], best[1-b_cur])
 __global__ __launch_bounds__(LIN_T) void linearize_loop_k(const IcpState *__restrict__ S, LoopBufs B,
-                                                          const int32_t *__restrict__ d_ns, int max_ns,
+                                                          const int32_t *__restrict__ d_ns,
                                                           const float *__restrict__ tgt, const float *__restrict__ nrm,
                                                           float thresh, float *__restrict__ partials) {
     const float *src = B.pts[1 - S->p_cur];
-    const unsigned long long *best = B.best[S->b_look];
-    unsigned long long *spare = B.best[S->b_spare];
+    const unsigned long long *best = B.best[1 - S->b_cur];
     const int ns = *d_ns;
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < max_ns; i += gridDim.x * LIN_T) {
-        spare[i] = KEY_NONE;
+    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
         const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
         if (r.valid) accumulate_row(r, acc);
     }
@@ -501,15 +540,7 @@ struct GradParams {
 __device__ __forceinline__ void adopt_look(IcpState *S, const float *lin) {
     for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
     S->p_cur = 1 - S->p_cur;
-    const int old = S->b_cur;
-    S->b_cur = S->b_look;
-    S->b_look = S->b_spare;  // cleared by the linearise launch that just ran
-    S->b_spare = old;
-}
-__device__ __forceinline__ void discard_look(IcpState *S) {
-    const int t = S->b_look;
-    S->b_look = S->b_spare;
-    S->b_spare = t;
+    S->b_cur = 1 - S->b_cur;
 }
 
 // Reduces the partials of the association + linearise launches that just ran and advances the LM /
@@ -546,8 +577,7 @@ __global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ S, cons
             S->damp = S->damp / 2.0f;
             mm4(S->dT, S->T, S->T);
         } else {
-            discard_look(S);
-            S->damp = S->damp * 2.0f;
+            S->damp = S->damp * 2.0f;  // the look-ahead buffers are simply overwritten next time
         }
         S->it += 1;
         solve6(S->cur, S->cur + 36, S->damp, S->xi);
@@ -569,8 +599,7 @@ __global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ S, cons
         for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
         se3_exp_dev(sx, S->dT);
         mm4(S->dT, S->T, S->T);
-        S->it += 1;
-        discard_look(S);  // the next launch re-derives the cloud from pts[p_cur] with the damped step
+        S->it += 1;  // the next launch re-derives the cloud from pts[p_cur] with the damped step
     }
     if (out_T)
         for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
@@ -581,8 +610,8 @@ __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, 
         for (int i = 0; i < 16; ++i) { S->T[i] = init_T[i]; S->dT[i] = init_T[i]; }
         for (int i = 0; i < 44; ++i) S->cur[i] = 0.0f;
         S->damp = damp;
-        S->p_cur = 1;  // the first association writes pts[0]
-        S->b_cur = 2; S->b_look = 0; S->b_spare = 1; S->b_first = 2;
+        S->p_cur = 1;  // the first association writes pts[0] / best[0]
+        S->b_cur = 1; S->b_first = 0;
         S->it = 0;
     }
 }
@@ -602,16 +631,6 @@ static inline int knn_nsplit_brute(int max_ns, int max_nt) {
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     if (ns > 4096) ns = 4096;
-    return ns;
-}
-// pruned search: aim at ~4 waves per SIMD over the chip, but never less than 8 chunks per range
-static inline int knn_nsplit_box(int max_ns, int max_nt) {
-    const int waves = cdiv(max_ns, 64);
-    int ns = cdiv(4096, waves);
-    const int cap = cdiv(cdiv(max_nt, CHUNK), 8);
-    if (ns > cap) ns = cap;
-    if (ns < 1) ns = 1;
-    if (ns > 64) ns = 64;
     return ns;
 }
 static inline int lin_blocks(int max_ns) {
@@ -657,7 +676,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t oS = take(sizeof(IcpState));
     const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
-    const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8), oB2 = take((size_t)max_ns * 8);
+    const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
     const size_t oPart = take((size_t)LIN_MAXB * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt));
     if (ws && out) {
@@ -666,7 +685,6 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
         out->B.pts[0] = (float *)(p + oP0); out->B.pts[1] = (float *)(p + oP1);
         out->B.best[0] = (unsigned long long *)(p + oB0);
         out->B.best[1] = (unsigned long long *)(p + oB1);
-        out->B.best[2] = (unsigned long long *)(p + oB2);
         out->partials = (float *)(p + oPart);
         out->boxes = (float *)(p + oBox);
     }
@@ -689,22 +707,19 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     }
     IcpWs w;
     icp_ws_layout(max_ns, max_nt, ws, &w);
-    const int nsplit = knn_nsplit_box(max_ns, max_nt);
-    const dim3 kgrid(cdiv(max_ns, KNN_T), nsplit);
+    const dim3 kgrid(cdiv(max_ns, 64));
     const int lb = lin_blocks(max_ns);
     const int fb = min(cdiv(max_ns, 256), 256);
 
     hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
-    hipLaunchKernelGGL(fill_u64_k, dim3(fb), dim3(256), 0, st, w.B.best[0], max_ns, KEY_NONE);
     hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, CHUNK)), dim3(64), 0, st, tgt, d_nt, w.boxes);
     GS_LAUNCH_CHECK(name);
     auto assoc = [&](int first) {
         prof_mark(0, 0, st);
-        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_T), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt, nsplit);
+        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt);
         prof_mark(0, 1, st);
         prof_mark(1, 0, st);
-        hipLaunchKernelGGL(linearize_loop_k, dim3(lb), dim3(LIN_T), 0, st, w.S, w.B, d_ns, max_ns, tgt, nrm, thresh,
-                           w.partials);
+        hipLaunchKernelGGL(linearize_loop_k, dim3(lb), dim3(LIN_T), 0, st, w.S, w.B, d_ns, tgt, nrm, thresh, w.partials);
         prof_mark(1, 1, st);
     };
     auto step = [&](int mode) {
@@ -775,18 +790,19 @@ int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
     GS_REQUIRE(max_ns >= 0 && max_nt >= 0, "gs_knn1: negative size");
     if (max_ns == 0) return GS_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fill_u64_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, st, (unsigned long long *)best, max_ns, KEY_NONE);
-    GS_LAUNCH_CHECK("gs_knn1/fill");
-    if (max_nt == 0) return GS_OK;
+    if (max_nt == 0) {
+        hipLaunchKernelGGL(fill_u64_k, dim3(min(cdiv(max_ns, 256), 1024)), dim3(256), 0, st, (unsigned long long *)best, max_ns, KEY_NONE);
+        GS_LAUNCH_CHECK("gs_knn1/fill");
+        return GS_OK;
+    }
     if (!ws || ws_bytes < boxes_bytes(max_nt)) {
         set_error("gs_knn1: workspace too small (%zu < %zu)", ws_bytes, boxes_bytes(max_nt));
         return GS_ERR_WORKSPACE_TOO_SMALL;
     }
     hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, CHUNK)), dim3(64), 0, st, tgt, d_nt, (float *)ws);
     GS_LAUNCH_CHECK("gs_knn1/boxes");
-    const int nsplit = knn_nsplit_box(max_ns, max_nt);
-    hipLaunchKernelGGL(knn1_box_k, dim3(cdiv(max_ns, KNN_T), nsplit), dim3(KNN_T), 0, st, src, d_ns, tgt, (const float *)ws,
-                       d_nt, nsplit, (unsigned long long *)best);
+    hipLaunchKernelGGL(knn1_box_k, dim3(cdiv(max_ns, 64)), dim3(KNN_BT), 0, st, src, d_ns, tgt, (const float *)ws, d_nt,
+                       (unsigned long long *)best);
     GS_LAUNCH_CHECK("gs_knn1");
     return GS_OK;
 }
