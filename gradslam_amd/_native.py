@@ -51,6 +51,10 @@ SIGNATURES = {
                                     c_p]),
     "gs_icp_point_to_plane_grad": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
                                          c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_compose_poses": (c_i, [c_p, c_p, c_i, c_p, c_p]),
+    "gs_slam_localize_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "gs_slam_localize": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f,
+                               c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_profile_enable": (None, [c_i]),
     "gs_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),
     "gs_fusion_similar": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),

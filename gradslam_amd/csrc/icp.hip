@@ -31,7 +31,6 @@ namespace gs {
 constexpr int KNN_T = 256;      // brute force: threads per block
 constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving the same 64 source points
 constexpr int KNN_BT = KNN_NW * 64;
-constexpr int KNN_ROUND = 2048; // chunks tested per round (= capacity of the LDS candidate list)
 constexpr int KNN_COARSE = 2048;// target points sampled by the seed pass when no seed is given
 constexpr int CHUNK = 64;       // target points per AABB chunk
 constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
@@ -96,26 +95,39 @@ __global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt,
 
 // Cooperative exact search of one 64-point source tile by the KNN_NW waves of a block.  Every wave
 // holds the same 64 source points (lane = point); the waves share the work over TARGET chunks:
-//   seed   : one real candidate per lane (given index, or the best of a strided sample of the target)
-//   round  : waves test disjoint chunk boxes against the lanes' current best and append the chunks that
-//            may still matter to an LDS list; then waves scan disjoint list entries; then the lanes' bests
-//            are merged across waves through LDS, which tightens the bound for the next round.
-// The critical path is (boxes + surviving points) / KNN_NW instead of a whole target range per wave.
+//   seed : one real candidate per lane (given index, or the best of a strided sample of the target)
+//   main : wave w owns chunks w, w+NW, w+2NW, ... (neighbouring chunks -- which tend to survive
+//          together -- land on different waves).  It loads its boxes with one strided vector load,
+//          tests them against the lanes' current best, and scans a surviving chunk straight away
+//          (one coalesced vector load, candidates broadcast with v_readlane).
+// The lanes' running best lives in LDS as packed keys: waves publish improvements with ds_min_u64 and
+// re-read before every test, so a hit found by one wave prunes the others' remaining chunks.  A stale
+// read only prunes less, never wrongly; two barriers in total.
 struct KnnShared {
-    unsigned long long key[KNN_NW][64];
-    int list[KNN_ROUND];
-    int cnt;
+    unsigned long long key[64];
 };
 
-__device__ __forceinline__ void knn_merge(KnnShared &sh, bool ok, float &bd, int &bi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    sh.key[wave][lane] = (ok && bd < INFINITY) ? pack_key(bd, bi) : KEY_NONE;
-    __syncthreads();
-    unsigned long long m = sh.key[0][lane];
-#pragma unroll
-    for (int w = 1; w < KNN_NW; ++w) m = min(m, sh.key[w][lane]);
-    __syncthreads();
-    if (m != KEY_NONE) { bd = bitsf((uint32_t)(m >> 32)); bi = (int)(uint32_t)(m & 0xffffffffu); }
+// wave-uniform broadcast of lane l's value (v_readlane_b32: no memory round trip)
+__device__ __forceinline__ float rlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// Test the n (<= 64) target points held one per lane in (px,py,pz) with target index pj against the
+// lane's source point s; branch-free (distance, index) lexicographic update.
+__device__ __forceinline__ void scan_held(const f3 s, const float px, const float py, const float pz, const int pj,
+                                          const int n, float &bd, int &bi) {
+    for (int k = 0; k < n; ++k) {
+        const float d = dist2(s, rlane(px, k), rlane(py, k), rlane(pz, k));
+        const int j = __builtin_amdgcn_readlane(pj, k);
+        const bool better = (d < bd) | ((d == bd) & (j < bi));
+        bd = better ? d : bd;
+        bi = better ? j : bi;
+    }
+}
+
+__device__ __forceinline__ void key_unpack(unsigned long long k, float &bd, int &bi) {
+    bd = (k == KEY_NONE) ? INFINITY : bitsf((uint32_t)(k >> 32));
+    bi = (k == KEY_NONE) ? 0x7fffffff : (int)(uint32_t)(k & 0xffffffffu);
 }
 
 // returns the packed key of lane's point (KEY_NONE when there is no target)
@@ -123,53 +135,63 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
                                                        const float *__restrict__ tgt, const float *__restrict__ boxes,
                                                        const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float bd = INFINITY;
-    int bi = 0;
-    if (seed_j >= 0) {
-        if (ok) {
+    if (wave == 0) {
+        unsigned long long k0 = KEY_NONE;
+        if (ok && seed_j >= 0) {
             const f3 q = ld3(tgt, seed_j);
-            bd = dist2(s, q.x, q.y, q.z);
-            bi = seed_j;
+            k0 = pack_key(dist2(s, q.x, q.y, q.z), seed_j);
         }
-    } else {
-        // seed pass: strided sample of the target, shared over the waves (wave-uniform loads)
+        sh.key[lane] = k0;
+    }
+    __syncthreads();
+    if (seed_j < 0) {
+        // seed pass: a strided sample of the target, KNN_COARSE / KNN_NW points per wave
         const int M = min(nt, KNN_COARSE);
-        for (int k = wave; k < M; k += KNN_NW) {
-            const int j = (int)(((long long)k * nt) / M);
-            const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
-            if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }
+        float bd = INFINITY;
+        int bi = 0x7fffffff;
+        for (int k0 = wave * 64; k0 < M; k0 += KNN_NW * 64) {
+            const int k = k0 + lane;
+            const int n = min(64, M - k0);
+            const int j = (k < M) ? (int)(((long long)k * nt) / M) : 0;
+            const f3 q = (k < M) ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
+            scan_held(s, q.x, q.y, q.z, j, n, bd, bi);
         }
-        knn_merge(sh, ok, bd, bi);
+        if (ok && bd < INFINITY) atomicMin(&sh.key[lane], pack_key(bd, bi));
+        __syncthreads();
     }
     const int nchunks = (nt + CHUNK - 1) / CHUNK;
-    for (int r0 = 0; r0 < nchunks; r0 += KNN_ROUND) {
-        if (threadIdx.x == 0) sh.cnt = 0;
-        __syncthreads();
-        const int r1 = min(nchunks, r0 + KNN_ROUND);
-        for (int c = r0 + wave; c < r1; c += KNN_NW) {
-            const float *b = boxes + 6 * c;  // wave-uniform -> scalar loads
-            // per-axis distance to the box, then the SAME accumulation order as dist2 (monotone rounding
-            // => the lower bound holds exactly in fp32)
-            const float ex = fmaxf(fmaxf(b[0] - s.x, s.x - b[3]), 0.0f);
-            const float ey = fmaxf(fmaxf(b[1] - s.y, s.y - b[4]), 0.0f);
-            const float ez = fmaxf(fmaxf(b[2] - s.z, s.z - b[5]), 0.0f);
+    for (int cb = wave; cb < nchunks; cb += KNN_NW * 64) {
+        // lane l holds the box of chunk cb + l*KNN_NW
+        const int c = cb + lane * KNN_NW;
+        const int n = min(64, (nchunks - cb + KNN_NW - 1) / KNN_NW);
+        float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+        if (c < nchunks) {
+            const float *b = boxes + 6 * (int64_t)c;
+            b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3]; b4 = b[4]; b5 = b[5];
+        }
+        for (int k = 0; k < n; ++k) {
+            float bd;
+            int bi;
+            key_unpack(sh.key[lane], bd, bi);
+            // per-axis distance to the box, then the SAME accumulation order as dist2 (monotone
+            // rounding => the lower bound holds exactly in fp32)
+            const float ex = fmaxf(fmaxf(rlane(b0, k) - s.x, s.x - rlane(b3, k)), 0.0f);
+            const float ey = fmaxf(fmaxf(rlane(b1, k) - s.y, s.y - rlane(b4, k)), 0.0f);
+            const float ez = fmaxf(fmaxf(rlane(b2, k) - s.z, s.z - rlane(b5, k)), 0.0f);
             const float lb = (ex * ex + ey * ey) + ez * ez;
-            // keep the chunk unless EVERY lane's bound is strictly above its best
-            if (__any(ok && lb <= bd) && lane == 0) sh.list[atomicAdd(&sh.cnt, 1)] = c;
+            // skip the chunk iff EVERY lane's bound is strictly above its best
+            if (!__any(ok & (lb <= bd))) continue;
+            const int j0 = (cb + k * KNN_NW) * CHUNK;
+            const int m = min(CHUNK, nt - j0);
+            const f3 q = (lane < m) ? ld3(tgt, j0 + lane) : f3{0.0f, 0.0f, 0.0f};
+            const float bd0 = bd;
+            const int bi0 = bi;
+            scan_held(s, q.x, q.y, q.z, j0 + lane, m, bd, bi);
+            if (ok && (bd < bd0 || bi < bi0)) atomicMin(&sh.key[lane], pack_key(bd, bi));
         }
-        __syncthreads();
-        const int n = sh.cnt;
-        for (int k = wave; k < n; k += KNN_NW) {
-            const int c = sh.list[k];
-            const int j0 = c * CHUNK, j1 = min(nt, j0 + CHUNK);
-            for (int j = j0; j < j1; ++j) {
-                const float d = dist2(s, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
-                if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }  // (distance, index) lexicographic
-            }
-        }
-        knn_merge(sh, ok, bd, bi);
     }
-    return (ok && bd < INFINITY) ? pack_key(bd, bi) : KEY_NONE;
+    __syncthreads();
+    return ok ? sh.key[lane] : KEY_NONE;
 }
 
 // Device-resident loop state.  Point clouds ping-pong between pts[0..1] and nearest-neighbour arrays
@@ -549,14 +571,11 @@ __device__ __forceinline__ void adopt_look(IcpState *S, const float *lin) {
 //                re-linearisation)                          -> solve ; dT = exp(xi)
 //   STEP_LM    : look-ahead cloud: accept (adopt, damp/2, T = dT T) or reject (damp*2) -> solve ; dT
 //   STEP_GRAD_B: look-ahead error -> damp, sigma ; dT = exp(sigma xi) ; T = dT T ; look-ahead discarded
-__global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ S, const float *__restrict__ partials, int nblocks,
-                                                  int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
-                                                  float *__restrict__ out_T) {
-    __shared__ float acc[NACC];
-    reduce_partials(partials, nblocks, acc);
-    if (threadIdx.x != 0) return;
+__device__ void step_update(IcpState *S, const float *acc, int mode, GradParams gp, float *__restrict__ trace,
+                            float *__restrict__ out_T) {
     float lin[44];
     expand44(acc, lin);
+
     if (mode == STEP_ADOPT) {
         adopt_look(S, lin);
         S->b_first = S->b_cur;
@@ -603,6 +622,19 @@ __global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ S, cons
     }
     if (out_T)
         for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
+}
+
+__global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
+                                                  int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
+                                                  float *__restrict__ out_T) {
+    __shared__ float acc[NACC];
+    __shared__ IcpState st;  // work on an LDS copy: ~200 dependent accesses at LDS, not HBM, latency
+    constexpr int kWords = sizeof(IcpState) / 4;
+    if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
+    reduce_partials(partials, nblocks, acc);  // ends with a barrier: st and acc are visible
+    if (threadIdx.x == 0) step_update(&st, acc, mode, gp, trace, out_T);
+    __syncthreads();
+    if (threadIdx.x < kWords) reinterpret_cast<int *>(Sg)[threadIdx.x] = reinterpret_cast<const int *>(&st)[threadIdx.x];
 }
 
 __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, float damp) {

@@ -1,0 +1,127 @@
+// slam.hip -- whole-step drivers: chains of the kernels of this library with every data-dependent size
+// kept on the device, so one C call enqueues a complete ICPSLAM._localize (reference
+// slam/icpslam.py:238-247) without a single host round trip.
+#include "gs_common.hpp"
+
+namespace gs {
+
+// kornia.geometry.linalg.compose_transformations semantics (call site reference slam/icpslam.py:245-247):
+// R = R01 R12 ; t = R01 t12 + t01 ; bottom row [0,0,0,1].   out[b] = T[b] . P[b]
+__global__ void compose_k(const float *__restrict__ T, const float *__restrict__ P, int B, float *__restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *a = T + 16 * b, *p = P + 16 * b;
+    float *o = out + 16 * b;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) o[4 * i + j] = dot3_fma(a[4 * i], a[4 * i + 1], a[4 * i + 2], p[j], p[4 + j], p[8 + j]);
+        o[4 * i + 3] = dot3_fma(a[4 * i], a[4 * i + 1], a[4 * i + 2], p[3], p[7], p[11]) + a[4 * i + 3];
+    }
+    o[12] = 0.0f; o[13] = 0.0f; o[14] = 0.0f; o[15] = 1.0f;
+}
+
+__global__ void eye4_k(float *__restrict__ T, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16 * B) T[i] = ((i % 16) % 5 == 0) ? 1.0f : 0.0f;
+}
+
+struct LocWs {
+    float *src;        // (B, capS, 3)
+    int32_t *ns;       // (B)
+    int64_t *rows;     // (B*Nmax, 4)
+    int32_t *nrows;    // (1)
+    float *tgt, *tnrm; // (B, capT, 3)
+    int32_t *nt;       // (B)
+    float *T;          // (B, 16) ICP result; eye (B,16) follows
+    float *eye;
+    void *sub;         // scratch shared by the sub-calls (they run one after the other on one stream)
+    size_t sub_bytes;
+};
+
+static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs *out) {
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = Nmax;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t o_src = take((size_t)B * capS * 12), o_ns = take((size_t)B * 4);
+    const size_t o_rows = take((size_t)B * Nmax * 32), o_nrows = take(4);
+    const size_t o_tgt = take((size_t)B * capT * 12), o_tnrm = take((size_t)B * capT * 12), o_nt = take((size_t)B * 4);
+    const size_t o_T = take((size_t)B * 64), o_eye = take((size_t)B * 64);
+    size_t sub = gs_downsample_frame_ws_bytes(H, W, ds);
+    sub = std::max(sub, gs_project_active_ws_bytes(B, Nmax));
+    sub = std::max(sub, gs_gather_table_rows_ws_bytes(B));
+    sub = std::max(sub, gs_icp_ws_bytes(capS, capT));
+    const size_t o_sub = take(sub);
+    if (ws && out) {
+        char *p = (char *)ws;
+        out->src = (float *)(p + o_src); out->ns = (int32_t *)(p + o_ns);
+        out->rows = (int64_t *)(p + o_rows); out->nrows = (int32_t *)(p + o_nrows);
+        out->tgt = (float *)(p + o_tgt); out->tnrm = (float *)(p + o_tnrm); out->nt = (int32_t *)(p + o_nt);
+        out->T = (float *)(p + o_T); out->eye = (float *)(p + o_eye);
+        out->sub = p + o_sub; out->sub_bytes = sub;
+    }
+    return off;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream) {
+    GS_REQUIRE(T && P && out && B > 0, "gs_compose_poses: bad arguments");
+    hipLaunchKernelGGL(compose_k, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, T, P, B, out);
+    GS_LAUNCH_CHECK("gs_compose_poses");
+    return GS_OK;
+}
+
+size_t gs_slam_localize_ws_bytes(int B, int H, int W, int ds, int Nmax) {
+    if (B <= 0 || H <= 0 || W <= 0 || ds <= 0 || Nmax <= 0) return 0;
+    return loc_layout(B, H, W, ds, Nmax, nullptr, nullptr);
+}
+
+int gs_slam_localize(const float *depth, const float *intrinsics, const float *prev_poses, int B, int H, int W, int ds,
+                     const float *map_points, const float *map_normals, const int32_t *map_counts, int Nmax,
+                     int use_grad_lm, int numiters, float damp, float dist_thresh, float lambda_max, float Bp, float B2,
+                     float nu, float *vertex, float *normal, float *gvertex, float *gnormal, float *out_poses, void *ws,
+                     size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(depth && intrinsics && prev_poses && map_points && map_normals && map_counts && gvertex && out_poses,
+               "gs_slam_localize: NULL argument (gvertex is required, the other maps are optional)");
+    GS_REQUIRE(B > 0 && H >= 2 && W >= 2 && ds > 0 && Nmax > 0 && numiters >= 0, "gs_slam_localize: bad shape");
+    if (!ws || ws_bytes < gs_slam_localize_ws_bytes(B, H, W, ds, Nmax)) {
+        set_error("gs_slam_localize: workspace too small (%zu < %zu)", ws_bytes, gs_slam_localize_ws_bytes(B, H, W, ds, Nmax));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LocWs w;
+    loc_layout(B, H, W, ds, Nmax, ws, &w);
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = Nmax;
+    int rc;
+    // live frame posed with the previous pose: maps, then the ds-grid source cloud
+    if ((rc = gs_vertex_normal_maps(depth, intrinsics, prev_poses, B, 1, H, W, vertex, normal, gvertex, gnormal, stream))) return rc;
+    if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.ns, w.sub,
+                                  w.sub_bytes, stream))) return rc;
+    // map points that land on the ds-grid of the previous frame: the ICP target
+    if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
+                                w.sub_bytes, stream))) return rc;
+    if ((rc = gs_gather_table_rows(w.rows, w.nrows, (int64_t)B * Nmax, map_points, B, Nmax, 3, capT, w.tgt, w.nt, w.sub,
+                                   w.sub_bytes, stream))) return rc;
+    if ((rc = gs_gather_table_rows(w.rows, w.nrows, (int64_t)B * Nmax, map_normals, B, Nmax, 3, capT, w.tnrm, w.nt, w.sub,
+                                   w.sub_bytes, stream))) return rc;
+    hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
+    GS_LAUNCH_CHECK("gs_slam_localize/eye");
+    for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
+        const float *src = w.src + (size_t)b * capS * 3;
+        const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
+        if (use_grad_lm)
+            rc = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                                            dist_thresh, lambda_max, Bp, B2, nu, w.T + 16 * b, nullptr, nullptr, w.sub,
+                                            w.sub_bytes, stream);
+        else
+            rc = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                                       dist_thresh, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, stream);
+        if (rc) return rc;
+    }
+    return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);
+}
+
+}  // extern "C"

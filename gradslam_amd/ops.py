@@ -374,6 +374,27 @@ def icp_device_loop(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_par
     return T, best, trace
 
 
+def slam_localize_raw(depth, K, prev_poses, map_points, map_normals, map_counts_i32, ds, numiters, damp, dist_thresh,
+                      grad_params=None):
+    """One fused, sync-free ICPSLAM._localize (reference slam/icpslam.py:238-247).
+    depth (B,1,H,W,1), K (B,1,4,4), prev_poses (B,1,4,4), map padded (B,Nmax,3) x2 + counts (B,) int32.
+    Returns (poses (B,1,4,4), V, N): the local maps are handed back so the caller can cache them."""
+    require_hip(depth, K, prev_poses, map_points, map_normals, map_counts_i32, op="slam_localize")
+    depth, K, prev = _f32c(depth.detach()), _f32c(K.detach()), _f32c(prev_poses.detach())
+    mp, mn = _f32c(map_points.detach()), _f32c(map_normals.detach())
+    B, _, H, W = depth.shape[:4]
+    Nmax = mp.shape[1]
+    dev = depth.device
+    V, N, gV = (torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(3))
+    out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+    ws = workspace(ws_bytes("gs_slam_localize_ws_bytes", B, H, W, int(ds), Nmax), dev, "localize")
+    lmax, Bp, B2, nu = grad_params if grad_params is not None else (2.0, 1.0, 1.0, 200.0)
+    call("gs_slam_localize", ptr(depth), ptr(K), ptr(prev), B, H, W, int(ds), ptr(mp), ptr(mn), ptr(map_counts_i32), Nmax,
+         1 if grad_params is not None else 0, int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp),
+         float(B2), float(nu), ptr(V), ptr(N), ptr(gV), None, ptr(out), ptr(ws), ws.numel(), stream())
+    return out, V, N
+
+
 # ---------------------------------------------------------------------------------------------- C / U / F / A
 def fusion_similar_raw(rows, n_rows_dev, max_rows, gV, gN, map_points, map_normals, dist_th, dot_th):
     """-> keep (max_rows,) uint8, max_dot (1,) float32 device."""

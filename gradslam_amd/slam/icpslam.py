@@ -88,6 +88,9 @@ class ICPSLAM(nn.Module):
             return live_frame.poses
 
         if self.odom in ["icp", "gradicp"]:
+            fused = self._localize_fused(pointclouds, live_frame, prev_frame)
+            if fused is not None:
+                return fused
             live_frame.poses = prev_frame.poses
             frames_pc = downsample_rgbdimages(live_frame, self.dsratio)
             # active-point search with the ds-grid filter fused in (find_active_map_points +
@@ -96,6 +99,28 @@ class ICPSLAM(nn.Module):
             maps_pc = _gather_by_table(pointclouds, rows[: int(cnt.item())], len(pointclouds))
             transform = self.odomprov.provide(maps_pc, frames_pc)
             return compose_transformations(transform.squeeze(1), prev_frame.poses.squeeze(1)).unsqueeze(1)
+
+    def _localize_fused(self, pointclouds: Pointclouds, live_frame: RGBDImages, prev_frame: RGBDImages):
+        """Sync-free single-call localisation (`gs_slam_localize`) when nothing needs gradients.  Same
+        results as the staged path below it; the staged path stays for autograd."""
+        from .. import ops
+
+        p = self.odomprov
+        tensors = (live_frame.depth_image, live_frame.intrinsics, prev_frame.poses)
+        if (not pointclouds.has_points or not pointclouds.has_normals or live_frame.channels_first
+                or not all(t.is_cuda for t in tensors) or len(pointclouds) != len(live_frame)):
+            return None
+        mp, mn = pointclouds.points_padded, pointclouds.normals_padded
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors + (mp, mn, live_frame.rgb_image)):
+            return None
+        gparams = (p.lambda_max, p.B, p.B2, p.nu) if self.odom == "gradicp" else None
+        poses, V, N = ops.slam_localize_raw(live_frame.depth_image, live_frame.intrinsics, prev_frame.poses, mp, mn,
+                                            pointclouds._counts_i32(), self.dsratio, p.numiters, p.damp, p.dist_thresh,
+                                            gparams)
+        live_frame._poses = prev_frame.poses  # what the reference leaves behind (:239)
+        live_frame._vertex_map, live_frame._normal_map = V, N  # pose-independent: reusable by _map
+        live_frame._global_vertex_map = live_frame._global_normal_map = None
+        return poses
 
     def _map(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool = False):
         return update_map_aggregate(pointclouds, live_frame, inplace)

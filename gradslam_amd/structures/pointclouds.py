@@ -126,8 +126,12 @@ class Pointclouds(object):
         return self._num_points_per_pointcloud
 
     def _counts_i32(self) -> torch.Tensor:
-        """int32 device copy of the per-batch counts, the form the kernels read."""
-        return self.num_points_per_pointcloud.to(torch.int32)
+        """int32 device copy of the per-batch counts, the form the kernels read (cached)."""
+        cached = getattr(self, "_counts_i32_cache", None)
+        if cached is None or cached[0] != self._counts:
+            cached = (list(self._counts), torch.tensor(self._counts, dtype=torch.int32, device=self.device))
+            self._counts_i32_cache = cached
+        return cached[1]
 
     @property
     def nonpad_mask(self):
@@ -174,6 +178,11 @@ class Pointclouds(object):
                 setattr(self, "_%s_padded" % a, None)
                 continue
             width = 3 if a != "features" else self.num_features
+            if self._B == 1:
+                # one cloud: the padded form IS the list item (a view, no copy of a 10^5..10^6-point map
+                # per frame); nothing in this package writes into either form in place
+                setattr(self, "_%s_padded" % a, lst[0].unsqueeze(0))
+                continue
             setattr(self, "_%s_padded" % a,
                     structutils.list_to_padded(lst, (self._N, width), pad_value=0.0, equisized=self.equisized))
 

@@ -185,6 +185,23 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
                                uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
                                gs_stream_t stream);
 
+/* ---------------------------------------------------------------- whole localisation step
+ * ICPSLAM._localize for odom in {icp, gradicp} (slam/icpslam.py:238-247) as ONE call with no host
+ * synchronisation: live-frame maps posed with the previous pose (rgbdimages.py:643-762), ds-grid
+ * source cloud (icputils.py:651-669), active map points on the ds-grid of the previous frame
+ * (fusionutils.py:247-282 + icputils.py:596-619), the (grad)ICP loop, and the pose composition
+ * T . prev_pose (kornia compose_transformations semantics).  depth (B,H,W) is ONE frame per batch
+ * element; prev_poses / out_poses are B x 16.  vertex / normal / gnormal (B,H,W,3) are optional outputs
+ * (NULL to skip), gvertex is required scratch/output.  use_grad_lm selects the gradLM variant. */
+int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream);
+size_t gs_slam_localize_ws_bytes(int B, int H, int W, int ds, int Nmax);
+int gs_slam_localize(const float *depth, const float *intrinsics, const float *prev_poses, int B,
+                     int H, int W, int ds, const float *map_points, const float *map_normals,
+                     const int32_t *map_counts, int Nmax, int use_grad_lm, int numiters, float damp,
+                     float dist_thresh, float lambda_max, float Bp, float B2, float nu,
+                     float *vertex, float *normal, float *gvertex, float *gnormal, float *out_poses,
+                     void *ws, size_t ws_bytes, gs_stream_t stream);
+
 /* Optional timing of the two hot kernels of the loops above with HIP events recorded on the launch
  * stream (used by bench.py for the roofline line; off by default).  gs_profile_read folds the events
  * recorded so far (caller synchronises first) and returns launches / total ms for tag 0 = association

@@ -442,6 +442,22 @@ def test_full_size_localize_vs_oracle(gs):
     assert rel_err(pcs.points_list[0].cpu(), cloud.points[0]) < 1e-6
 
 
+def test_fused_localize_equals_staged(gs, golden):
+    """gs_slam_localize (one sync-free C call) must reproduce the staged Python path bit for bit, for
+    icp and gradicp, on a ragged batch of 2."""
+    g = golden("msrd_b2s3")
+    frames = frames_from(g, gs)
+    for odom in ("icp", "gradicp"):
+        slam = gs.slam.PointFusion(odom=odom, dsratio=4, numiters=6, device=DEV)
+        with torch.no_grad():
+            pcs, _ = slam.step(gs.Pointclouds(device=DEV), frames[:, 0], None)
+            mk = lambda: gs.RGBDImages(d(g["colors"][:, 1:2]), d(g["depths"][:, 1:2]), d(g["intrinsics"]))
+            fused = slam._localize(pcs, mk(), frames[:, 0])
+            slam._localize_fused = lambda *a: None  # force the staged path
+            staged = slam._localize(pcs, mk(), frames[:, 0])
+        assert torch.equal(fused, staged), odom
+
+
 # ------------------------------------------------------------------ BASELINE sizes: properties
 def test_full_size_properties(gs):
     """640x480: size-independent properties (the oracle would take minutes here)."""
