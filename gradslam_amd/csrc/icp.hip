@@ -46,6 +46,66 @@ __device__ __forceinline__ float dist2(f3 s, float tx, float ty, float tz) {
     return (dx * dx + dy * dy) + dz * dz;  // contraction off: x->y->z, no fma
 }
 
+// ------------------------------------------------------------------ J: row algebra (shared by K's epilogue)
+struct Row {
+    float a[6], b;
+    bool valid;
+};
+
+// reference odometry/icputils.py:203-230; every product / difference is rounded on its own
+// (elementwise torch ops), so nothing here may fuse.
+__device__ __forceinline__ Row make_row(const float *__restrict__ src, const float *__restrict__ tgt,
+                                        const float *__restrict__ nrm, const unsigned long long *__restrict__ best,
+                                        int i, int ns, float thresh) {
+    Row r;
+    r.valid = false;
+    if (i >= ns) return r;
+    const unsigned long long key = best[i];
+    if (key == KEY_NONE) return r;  // no target at all
+    const uint32_t j = (uint32_t)(key & 0xffffffffu);
+    const float d2 = bitsf((uint32_t)(key >> 32));
+    if (thresh >= 0.0f && !(d2 < thresh)) return r;  // NB squared distance vs threshold
+    const f3 s = ld3(src, i), d = ld3(tgt, j), n = ld3(nrm, j);
+    r.a[0] = n.x; r.a[1] = n.y; r.a[2] = n.z;
+    r.a[3] = n.z * s.y - n.y * s.z;
+    r.a[4] = n.x * s.z - n.z * s.x;
+    r.a[5] = n.y * s.x - n.x * s.y;
+    r.b = (n.x * (d.x - s.x) + n.y * (d.y - s.y)) + n.z * (d.z - s.z);
+    r.valid = true;
+    return r;
+}
+
+__device__ __forceinline__ void accumulate_row(const Row &r, float *acc) {
+    int q = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
+    acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
+    acc[28] += 1.0f;
+}
+
+// same row from values already in registers (the association kernel's epilogue)
+__device__ __forceinline__ Row make_row_from(const f3 s, const bool ok, const unsigned long long key,
+                                             const float *__restrict__ tgt, const float *__restrict__ nrm, float thresh) {
+    Row r;
+    r.valid = false;
+    if (!ok || key == KEY_NONE) return r;
+    const uint32_t j = (uint32_t)(key & 0xffffffffu);
+    const float d2 = bitsf((uint32_t)(key >> 32));
+    if (thresh >= 0.0f && !(d2 < thresh)) return r;
+    const f3 d = ld3(tgt, j), n = ld3(nrm, j);
+    r.a[0] = n.x; r.a[1] = n.y; r.a[2] = n.z;
+    r.a[3] = n.z * s.y - n.y * s.z;
+    r.a[4] = n.x * s.z - n.z * s.x;
+    r.a[5] = n.y * s.x - n.x * s.y;
+    r.b = (n.x * (d.x - s.x) + n.y * (d.y - s.y)) + n.z * (d.z - s.z);
+    r.valid = true;
+    return r;
+}
+
 // ------------------------------------------------------------------ K: brute force (verifier / tiny inputs)
 __global__ __launch_bounds__(KNN_T) void knn1_brute_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
                                                       const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
@@ -219,11 +279,16 @@ struct LoopBufs {
 __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S, int first,
                                                       const float *__restrict__ user_src, LoopBufs B,
                                                       const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
-                                                      const float *__restrict__ boxes, const int32_t *__restrict__ d_nt) {
+                                                      const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
+                                                      const float *__restrict__ nrm, float thresh,
+                                                      float *__restrict__ partials /* gridDim.x x NACC */) {
     __shared__ KnnShared sh;
     const int ns = *d_ns, nt = *d_nt;
     const int tile0 = blockIdx.x * 64;
-    if (tile0 >= ns) return;
+    if (tile0 >= ns) {  // empty tile: its partial row must still be defined
+        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
+        return;
+    }
     const int p_cur = S->p_cur, b_cur = S->b_cur;
     const float *in = first ? user_src : B.pts[p_cur];
     float *out = B.pts[1 - p_cur];
@@ -238,6 +303,7 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
     }
     if (nt <= 0) {
         if (ok && wave == 0) best[i] = KEY_NONE;
+        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
         return;
     }
     int sj = -1;
@@ -249,7 +315,20 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
         }
     }
     const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, boxes, nt);
-    if (ok && wave == 0) best[i] = key;
+    if (wave != 0) return;
+    if (ok) best[i] = key;
+    // linearise this tile straight away (J fused into K's epilogue): 29 partial sums per 64-point tile
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    const Row r = make_row_from(s, ok, key, tgt, nrm, thresh);
+    if (r.valid) accumulate_row(r, acc);
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
+    float mine = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) mine = (lane == k) ? acc[k] : mine;
+    if (lane < NACC) partials[blockIdx.x * NACC + lane] = mine;
 }
 
 // Stand-alone pruned search (gs_knn1): no transform, sampled seed pass.
@@ -286,47 +365,7 @@ __global__ void fill_u64_k(unsigned long long *__restrict__ p, int n, unsigned l
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
-// ------------------------------------------------------------------ J
-struct Row {
-    float a[6], b;
-    bool valid;
-};
-
-// reference odometry/icputils.py:203-230; every product / difference is rounded on its own
-// (elementwise torch ops), so nothing here may fuse.
-__device__ __forceinline__ Row make_row(const float *__restrict__ src, const float *__restrict__ tgt,
-                                        const float *__restrict__ nrm, const unsigned long long *__restrict__ best,
-                                        int i, int ns, float thresh) {
-    Row r;
-    r.valid = false;
-    if (i >= ns) return r;
-    const unsigned long long key = best[i];
-    if (key == KEY_NONE) return r;  // no target at all
-    const uint32_t j = (uint32_t)(key & 0xffffffffu);
-    const float d2 = bitsf((uint32_t)(key >> 32));
-    if (thresh >= 0.0f && !(d2 < thresh)) return r;  // NB squared distance vs threshold
-    const f3 s = ld3(src, i), d = ld3(tgt, j), n = ld3(nrm, j);
-    r.a[0] = n.x; r.a[1] = n.y; r.a[2] = n.z;
-    r.a[3] = n.z * s.y - n.y * s.z;
-    r.a[4] = n.x * s.z - n.z * s.x;
-    r.a[5] = n.y * s.x - n.x * s.y;
-    r.b = (n.x * (d.x - s.x) + n.y * (d.y - s.y)) + n.z * (d.z - s.z);
-    r.valid = true;
-    return r;
-}
-
-__device__ __forceinline__ void accumulate_row(const Row &r, float *acc) {
-    int q = 0;
-#pragma unroll
-    for (int u = 0; u < 6; ++u)
-#pragma unroll
-        for (int v = u; v < 6; ++v) { acc[q] = __fmaf_rn(r.a[u], r.a[v], acc[q]); ++q; }
-#pragma unroll
-    for (int u = 0; u < 6; ++u) acc[21 + u] = __fmaf_rn(r.a[u], r.b, acc[21 + u]);
-    acc[27] = __fmaf_rn(r.b, r.b, acc[27]);
-    acc[28] += 1.0f;
-}
-
+// ------------------------------------------------------------------ J: stand-alone kernels
 // block-level fixed-order reduction of the 29 accumulators -> partials[blockIdx.x]
 __device__ __forceinline__ void block_reduce_store(float *acc, float *__restrict__ partials) {
     __shared__ float sm[LIN_T / 64][NACC];
@@ -349,24 +388,6 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
                                                      const float *__restrict__ tgt, const float *__restrict__ nrm,
                                                      const unsigned long long *__restrict__ best, float thresh,
                                                      float *__restrict__ partials /* gridDim.x x NACC */) {
-    const int ns = *d_ns;
-    float acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    for (int i = blockIdx.x * LIN_T + threadIdx.x; i < ns; i += gridDim.x * LIN_T) {
-        const Row r = make_row(src, tgt, nrm, best, i, ns, thresh);
-        if (r.valid) accumulate_row(r, acc);
-    }
-    block_reduce_store(acc, partials);
-}
-
-// linearise the cloud the association launch just produced (pts[1-p_cur], best[1-b_cur])
-__global__ __launch_bounds__(LIN_T) void linearize_loop_k(const IcpState *__restrict__ S, LoopBufs B,
-                                                          const int32_t *__restrict__ d_ns,
-                                                          const float *__restrict__ tgt, const float *__restrict__ nrm,
-                                                          float thresh, float *__restrict__ partials) {
-    const float *src = B.pts[1 - S->p_cur];
-    const unsigned long long *best = B.best[1 - S->b_cur];
     const int ns = *d_ns;
     float acc[NACC];
 #pragma unroll
@@ -709,7 +730,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oS = take(sizeof(IcpState));
     const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
-    const size_t oPart = take((size_t)LIN_MAXB * NACC * 4);
+    const size_t oPart = take((size_t)cdiv(max_ns, 64) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt));
     if (ws && out) {
         char *p = (char *)ws;
@@ -740,7 +761,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     IcpWs w;
     icp_ws_layout(max_ns, max_nt, ws, &w);
     const dim3 kgrid(cdiv(max_ns, 64));
-    const int lb = lin_blocks(max_ns);
+    const int lb = (int)kgrid.x;  // one partial row per 64-point tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
 
     hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
@@ -748,11 +769,9 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     GS_LAUNCH_CHECK(name);
     auto assoc = [&](int first) {
         prof_mark(0, 0, st);
-        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt);
+        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt, nrm, thresh,
+                           w.partials);
         prof_mark(0, 1, st);
-        prof_mark(1, 0, st);
-        hipLaunchKernelGGL(linearize_loop_k, dim3(lb), dim3(LIN_T), 0, st, w.S, w.B, d_ns, tgt, nrm, thresh, w.partials);
-        prof_mark(1, 1, st);
     };
     auto step = [&](int mode) {
         hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(256), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T);
