@@ -99,6 +99,27 @@ def hbm_roofline_linearize(gs, dev, n_pts=1 << 24, reps=20):
             "note": "peak = 8.0 TB/s HBM3E spec (6.29 TB/s is the measured float4-copy ceiling)"}
 
 
+def aux_pointfusion(gs, dev, raw, n_frames=30):
+    """Auxiliary, NOT part of `value`: forward frames/s of the full PointFusion step (localise + map update,
+    BASELINE configs[2] shape) over a short synthetic sequence, map growing from empty."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, d, K, P = make_sequence(1, n_frames, H, W, seed=100)
+    frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
+    slam = gs.slam.PointFusion(odom="icp", dsratio=DS, numiters=ITERS, device=dev)
+    with torch.no_grad():
+        slam(gs.RGBDImages(c[:, :3].to(dev), d[:, :3].to(dev), K.to(dev), P[:, :3].to(dev)))  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pcs, poses = slam(frames)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    err = float((poses.cpu() - P).abs().max())
+    return {"pointfusion_c3_forward_fps": round(n_frames / dt, 2), "frames": n_frames,
+            "final_map_points": int(pcs.num_points_per_pointcloud.item()), "pose_max_abs_err_vs_gt": round(err, 5),
+            "note": "PointFusion(odom='icp') forward over a 640x480 synthetic sequence, not part of `value`"}
+
+
 def cpu_baseline(raw, n_frames=24):
     """The CPU oracle (kind 'port') on the same workload: localise live frames 1..n against the map."""
     from oracle import fusion as ofu
@@ -211,6 +232,11 @@ def main():
             line["roofline_hbm"] = hbm_roofline_linearize(gs, dev)
         except Exception as e:  # pragma: no cover
             line["roofline_hbm"] = {"error": str(e)}
+        if world == 1:
+            try:
+                line["aux"] = aux_pointfusion(gs, dev, raw)
+            except Exception as e:  # pragma: no cover
+                line["aux"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raw)
         print(json.dumps(line), flush=True)

@@ -31,8 +31,9 @@ namespace gs {
 constexpr int KNN_T = 256;      // brute force: threads per block
 constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving the same 64 source points
 constexpr int KNN_BT = KNN_NW * 64;
-constexpr int KNN_COARSE = 2048;// target points sampled by the seed pass when no seed is given
-constexpr int CHUNK = 64;       // target points per AABB chunk
+constexpr int KNN_COARSE = 512; // target points sampled by the seed pass when no seed is given
+constexpr int CHUNK = 16;       // target points per AABB chunk
+constexpr int KNN_LIST = 4096;  // chunk boxes handled per round (capacity of the LDS survivor list)
 constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
 constexpr int LIN_MAXB = 1024;  // max partial blocks
@@ -127,13 +128,13 @@ __global__ __launch_bounds__(KNN_T) void knn1_brute_k(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------ K: AABB-pruned exact search
-// boxes: per chunk 6 floats (lo.xyz, hi.xyz)
+// boxes: per chunk 6 floats (lo.xyz, hi.xyz).  One wave covers 64 target points = 64/CHUNK chunks
+// (segmented butterfly inside each CHUNK-lane group).
 __global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
                                                   float *__restrict__ boxes) {
     const int nt = *d_nt;
-    const int c = blockIdx.x;
-    const int j = c * CHUNK + threadIdx.x;
-    if (c * CHUNK >= nt) return;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= nt) return;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (j < nt) {
         const f3 p = ld3(tgt, j);
@@ -142,34 +143,70 @@ __global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt,
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = CHUNK / 2; off > 0; off >>= 1) {
             lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, kWave));
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, kWave));
         }
     }
-    if (threadIdx.x == 0) {
-        float *b = boxes + 6 * c;
+    if ((threadIdx.x % CHUNK) == 0 && j < nt) {
+        float *b = boxes + 6 * (int64_t)(j / CHUNK);
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
     }
 }
 
 // Cooperative exact search of one 64-point source tile by the KNN_NW waves of a block.  Every wave
 // holds the same 64 source points (lane = point); the waves share the work over TARGET chunks:
-//   seed : one real candidate per lane (given index, or the best of a strided sample of the target)
-//   main : wave w owns chunks w, w+NW, w+2NW, ... (neighbouring chunks -- which tend to survive
-//          together -- land on different waves).  It loads its boxes with one strided vector load,
-//          tests them against the lanes' current best, and scans a surviving chunk straight away
-//          (one coalesced vector load, candidates broadcast with v_readlane).
+//   seed   : one real candidate per lane (given index, or the best of a strided sample of the target)
+//   coarse : lanes = chunk boxes.  A chunk survives iff the gap between ITS box and the TILE's box is not
+//            above the largest seed distance of the tile: 64 boxes per wave-instruction, ~1 instruction
+//            sequence per wave for a whole 19 k-point target.
+//   fine   : surviving chunks are dealt round-robin to the waves; each is tested against every lane's
+//            own bound (lanes = source points) and, if some lane still needs it, scanned: one coalesced
+//            load of its CHUNK points, candidates broadcast with v_readlane.
 // The lanes' running best lives in LDS as packed keys: waves publish improvements with ds_min_u64 and
-// re-read before every test, so a hit found by one wave prunes the others' remaining chunks.  A stale
-// read only prunes less, never wrongly; two barriers in total.
+// re-read before every fine test, so a hit found by one wave prunes the others' remaining chunks.  A
+// stale read only prunes less, never wrongly.  All bounds use the distance's own operation order, so
+// bound <= distance holds exactly in fp32 (monotone rounding): the result is the brute-force scan's.
 struct KnnShared {
     unsigned long long key[64];
+    int list[KNN_LIST];
+    int cnt;
+    float tbox[6];             // the source tile's AABB (lo.xyz, hi.xyz)
+    float rows[NACC][65];      // linearise epilogue: per-point products, padded against bank conflicts
+    float part[NACC][16];
 };
+
+#ifdef GS_DIAG_STAMPS
+// Diagnostic build only (libgradslam_hip_diag.so, never loaded by the product): per-wave phase stamps.
+__device__ unsigned long long *g_diag = nullptr;
+#define GS_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if (g_diag && (threadIdx.x & 63) == 0)                                                           \
+            g_diag[((size_t)blockIdx.x * KNN_NW + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64();    \
+    } while (0)
+#define GS_COUNT(slot, v)                                                                                \
+    do {                                                                                                 \
+        if (g_diag && (threadIdx.x & 63) == 0)                                                           \
+            g_diag[((size_t)blockIdx.x * KNN_NW + (threadIdx.x >> 6)) * 8 + (slot)] = (v);              \
+    } while (0)
+#else
+#define GS_STAMP(slot)
+#define GS_COUNT(slot, v)
+#endif
 
 // wave-uniform broadcast of lane l's value (v_readlane_b32: no memory round trip)
 __device__ __forceinline__ float rlane(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
 }
 
 // Test the n (<= 64) target points held one per lane in (px,py,pz) with target index pj against the
@@ -195,6 +232,8 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
                                                        const float *__restrict__ tgt, const float *__restrict__ boxes,
                                                        const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    GS_STAMP(0);
+    int n_scanned = 0;
     if (wave == 0) {
         unsigned long long k0 = KEY_NONE;
         if (ok && seed_j >= 0) {
@@ -203,54 +242,130 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
         }
         sh.key[lane] = k0;
     }
+    if (wave >= 1 && wave <= 6) {  // the tile's box: one wave per component, published through LDS
+        const int a = wave - 1;
+        const float v = (a % 3 == 0) ? s.x : ((a % 3 == 1) ? s.y : s.z);
+        const float r = (a < 3) ? wave_min_f(ok ? v : INFINITY) : wave_max_f(ok ? v : -INFINITY);
+        if (lane == 0) sh.tbox[a] = r;
+    }
     __syncthreads();
     if (seed_j < 0) {
-        // seed pass: a strided sample of the target, KNN_COARSE / KNN_NW points per wave
+        // seed pass 1: a strided sample of KNN_COARSE target points, 16 per wave and step (uniform broadcast)
         const int M = min(nt, KNN_COARSE);
+        const float stride = (float)nt / (float)M;
         float bd = INFINITY;
         int bi = 0x7fffffff;
-        for (int k0 = wave * 64; k0 < M; k0 += KNN_NW * 64) {
+        for (int k0 = wave * 16; k0 < M; k0 += KNN_NW * 16) {
             const int k = k0 + lane;
-            const int n = min(64, M - k0);
-            const int j = (k < M) ? (int)(((long long)k * nt) / M) : 0;
-            const f3 q = (k < M) ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
+            const int n = min(16, M - k0);
+            const int j = min((int)((float)k * stride), nt - 1);
+            const f3 q = (lane < n) ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
             scan_held(s, q.x, q.y, q.z, j, n, bd, bi);
         }
         if (ok && bd < INFINITY) atomicMin(&sh.key[lane], pack_key(bd, bi));
         __syncthreads();
+        // seed pass 2: clouds are image ordered, so index neighbours of the best sample are spatial
+        // neighbours: each lane refines over [j*-R, j*+R) of ITS sample, the waves split the offsets
+        constexpr int R = 64;
+        key_unpack(sh.key[lane], bd, bi);
+        const int jstar = bi;
+        for (int t = 0; t < 2 * R / KNN_NW; ++t) {
+            const int j = min(max(jstar - R + wave * (2 * R / KNN_NW) + t, 0), nt - 1);
+            const f3 q = ok ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
+            const float d = dist2(s, q.x, q.y, q.z);
+            const bool better = (d < bd) | ((d == bd) & (j < bi));
+            bd = better ? d : bd;
+            bi = better ? j : bi;
+        }
+        if (ok && bi != jstar) atomicMin(&sh.key[lane], pack_key(bd, bi));
+        __syncthreads();
     }
+    GS_STAMP(1);
+    // the tile's box (from LDS) and its loosest bound (same 64 points in every wave -> same value)
+    float bd0;
+    int bi0;
+    key_unpack(sh.key[lane], bd0, bi0);
+    const float tlx = sh.tbox[0], tly = sh.tbox[1], tlz = sh.tbox[2];
+    const float thx = sh.tbox[3], thy = sh.tbox[4], thz = sh.tbox[5];
+    const float bdmax = wave_max_f(ok ? bd0 : 0.0f);
+
     const int nchunks = (nt + CHUNK - 1) / CHUNK;
-    for (int cb = wave; cb < nchunks; cb += KNN_NW * 64) {
-        // lane l holds the box of chunk cb + l*KNN_NW
-        const int c = cb + lane * KNN_NW;
-        const int n = min(64, (nchunks - cb + KNN_NW - 1) / KNN_NW);
-        float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-        if (c < nchunks) {
-            const float *b = boxes + 6 * (int64_t)c;
-            b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3]; b4 = b[4]; b5 = b[5];
+    for (int r0 = 0; r0 < nchunks; r0 += KNN_LIST) {
+        if (threadIdx.x == 0) sh.cnt = 0;
+        __syncthreads();
+        const int r1 = min(nchunks, r0 + KNN_LIST);
+        // coarse: lanes = chunk boxes; box-to-box gap with the distance's accumulation order
+        for (int c0 = r0 + wave * 64; c0 < r1; c0 += KNN_NW * 64) {
+            const int c = c0 + lane;
+            bool pass = false;
+            if (c < r1) {
+                const float *b = boxes + 6 * (int64_t)c;
+                const float ex = fmaxf(fmaxf(b[0] - thx, tlx - b[3]), 0.0f);
+                const float ey = fmaxf(fmaxf(b[1] - thy, tly - b[4]), 0.0f);
+                const float ez = fmaxf(fmaxf(b[2] - thz, tlz - b[5]), 0.0f);
+                pass = ((ex * ex + ey * ey) + ez * ez) <= bdmax;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh.cnt, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (pass) sh.list[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+            }
         }
-        for (int k = 0; k < n; ++k) {
-            float bd;
-            int bi;
-            key_unpack(sh.key[lane], bd, bi);
-            // per-axis distance to the box, then the SAME accumulation order as dist2 (monotone
-            // rounding => the lower bound holds exactly in fp32)
-            const float ex = fmaxf(fmaxf(rlane(b0, k) - s.x, s.x - rlane(b3, k)), 0.0f);
-            const float ey = fmaxf(fmaxf(rlane(b1, k) - s.y, s.y - rlane(b4, k)), 0.0f);
-            const float ez = fmaxf(fmaxf(rlane(b2, k) - s.z, s.z - rlane(b5, k)), 0.0f);
-            const float lb = (ex * ex + ey * ey) + ez * ez;
-            // skip the chunk iff EVERY lane's bound is strictly above its best
-            if (!__any(ok & (lb <= bd))) continue;
-            const int j0 = (cb + k * KNN_NW) * CHUNK;
-            const int m = min(CHUNK, nt - j0);
-            const f3 q = (lane < m) ? ld3(tgt, j0 + lane) : f3{0.0f, 0.0f, 0.0f};
-            const float bd0 = bd;
-            const int bi0 = bi;
-            scan_held(s, q.x, q.y, q.z, j0 + lane, m, bd, bi);
-            if (ok && (bd < bd0 || bi < bi0)) atomicMin(&sh.key[lane], pack_key(bd, bi));
+        __syncthreads();
+        // fine: survivors dealt round-robin to the waves, handled four at a time: ONE round of loads
+        // brings the boxes and the 4 x CHUNK candidate points of a group into registers (lane l holds
+        // point l%CHUNK of the group's survivor l/CHUNK), then tests and scans run without memory ops
+        const int nlist = sh.cnt;
+        const int ni = (nlist > wave) ? (nlist - wave + KNN_NW - 1) / KNN_NW : 0;
+        constexpr int SEG = 64 / CHUNK;
+        for (int g = 0; g < ni; g += SEG) {
+            const int seg = lane / CHUNK, idx = g + seg;
+            const bool have = idx < ni;
+            const int c = have ? sh.list[wave + KNN_NW * idx] : 0;
+            const int j = c * CHUNK + (lane % CHUNK);
+            const bool pv = have && j < nt;
+            const f3 q = pv ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
+            float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+            if (have) {
+                const float *b = boxes + 6 * (int64_t)c;
+                b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3]; b4 = b[4]; b5 = b[5];
+            }
+            const int ng = min(SEG, ni - g);
+            for (int sg = 0; sg < ng; ++sg) {
+                const int l0 = sg * CHUNK;
+                float bd;
+                int bi;
+                key_unpack(sh.key[lane], bd, bi);
+                const float ex = fmaxf(fmaxf(rlane(b0, l0) - s.x, s.x - rlane(b3, l0)), 0.0f);
+                const float ey = fmaxf(fmaxf(rlane(b1, l0) - s.y, s.y - rlane(b4, l0)), 0.0f);
+                const float ez = fmaxf(fmaxf(rlane(b2, l0) - s.z, s.z - rlane(b5, l0)), 0.0f);
+                const float lb = (ex * ex + ey * ey) + ez * ez;
+                // skip the chunk iff EVERY lane's bound is strictly above its best
+                if (!__any(ok & (lb <= bd))) continue;
+                const int cc = __builtin_amdgcn_readlane(c, l0);
+                const int m = min(CHUNK, nt - cc * CHUNK);
+                const float bdp = bd;
+                const int bip = bi;
+                for (int k = 0; k < m; ++k) {
+                    const float d = dist2(s, rlane(q.x, l0 + k), rlane(q.y, l0 + k), rlane(q.z, l0 + k));
+                    const int jj = cc * CHUNK + k;
+                    const bool better = (d < bd) | ((d == bd) & (jj < bi));
+                    bd = better ? d : bd;
+                    bi = better ? jj : bi;
+                }
+                if (ok && (bd < bdp || bi < bip)) atomicMin(&sh.key[lane], pack_key(bd, bi));
+                ++n_scanned;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
+    GS_STAMP(2);
+    GS_COUNT(4, (unsigned long long)n_scanned);
+    GS_COUNT(5, (unsigned long long)sh.cnt);
+    (void)n_scanned;
+    GS_STAMP(3);
     return ok ? sh.key[lane] : KEY_NONE;
 }
 
@@ -315,20 +430,30 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
         }
     }
     const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, boxes, nt);
-    if (wave != 0) return;
-    if (ok) best[i] = key;
-    // linearise this tile straight away (J fused into K's epilogue): 29 partial sums per 64-point tile
-    float acc[NACC];
+    // linearise this tile straight away (J fused into K's epilogue): 29 sums over the tile's 64 points,
+    // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
+    if (wave == 0) {
+        if (ok) best[i] = key;
+        float acc[NACC];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    const Row r = make_row_from(s, ok, key, tgt, nrm, thresh);
-    if (r.valid) accumulate_row(r, acc);
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+        const Row r = make_row_from(s, ok, key, tgt, nrm, thresh);
+        if (r.valid) accumulate_row(r, acc);
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
-    float mine = 0.0f;
+        for (int k = 0; k < NACC; ++k) sh.rows[k][lane] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC * 16) {
+        const int k = threadIdx.x >> 4, p4 = (threadIdx.x & 15) * 4;
+        sh.part[k][threadIdx.x & 15] = ((sh.rows[k][p4] + sh.rows[k][p4 + 1]) + sh.rows[k][p4 + 2]) + sh.rows[k][p4 + 3];
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        float v = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) mine = (lane == k) ? acc[k] : mine;
-    if (lane < NACC) partials[blockIdx.x * NACC + lane] = mine;
+        for (int q = 0; q < 16; ++q) v += sh.part[threadIdx.x][q];
+        partials[blockIdx.x * NACC + threadIdx.x] = v;
+    }
 }
 
 // Stand-alone pruned search (gs_knn1): no transform, sampled seed pass.
@@ -765,7 +890,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int fb = min(cdiv(max_ns, 256), 256);
 
     hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
-    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, CHUNK)), dim3(64), 0, st, tgt, d_nt, w.boxes);
+    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, tgt, d_nt, w.boxes);
     GS_LAUNCH_CHECK(name);
     auto assoc = [&](int first) {
         prof_mark(0, 0, st);
@@ -809,6 +934,12 @@ using namespace gs;
 
 extern "C" {
 
+#ifdef GS_DIAG_STAMPS
+int gs_diag_set_buffer(void *p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &p, sizeof(p));
+}
+#endif
+
 void gs_profile_enable(int on) {
     g_prof.on = on != 0;
     for (int t = 0; t < 2; ++t) { g_prof.used[t] = 0; g_prof.total_ms[t] = 0.0; g_prof.count[t] = 0; }
@@ -850,7 +981,7 @@ int gs_knn1(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
         set_error("gs_knn1: workspace too small (%zu < %zu)", ws_bytes, boxes_bytes(max_nt));
         return GS_ERR_WORKSPACE_TOO_SMALL;
     }
-    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, CHUNK)), dim3(64), 0, st, tgt, d_nt, (float *)ws);
+    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, tgt, d_nt, (float *)ws);
     GS_LAUNCH_CHECK("gs_knn1/boxes");
     hipLaunchKernelGGL(knn1_box_k, dim3(cdiv(max_ns, 64)), dim3(KNN_BT), 0, st, src, d_ns, tgt, (const float *)ws, d_nt,
                        (unsigned long long *)best);
