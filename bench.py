@@ -173,6 +173,7 @@ def main():
     rank, world, local = parallel.init_from_env()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    local = local % max(torch.cuda.device_count(), 1)  # rehearsals may put several ranks on one card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nv.lib()
@@ -202,7 +203,8 @@ def main():
     n_knn, ms_knn = prof_read(nv, 0)
     nv.lib().gs_profile_enable(0)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    red_dev = "cpu" if (world > 1 and torch.distributed.get_backend() == "gloo") else dev
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -156,7 +156,7 @@ class _MaskSelectFn(torch.autograd.Function):
     def backward(ctx, g):
         (mask,) = ctx.saved_tensors
         out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
-        out[mask] = g  # adjoint of a gather with unique targets; tiny host-side index op
+        out[mask.bool() if mask.dtype != torch.bool else mask] = g  # adjoint of a gather with unique targets
         return out, None
 
 

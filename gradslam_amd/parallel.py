@@ -26,7 +26,7 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("GS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -49,12 +49,15 @@ def gather_poses(local_poses: torch.Tensor, batch: int) -> torch.Tensor:
         return local_poses
     world = dist.get_world_size()
     L = local_poses.shape[1]
+    dev = local_poses.device
+    # gloo (CPU rehearsal of the multi-rank path) gathers host tensors; RCCL gathers in HBM over xGMI
+    xdev = torch.device("cpu") if dist.get_backend() == "gloo" else dev
     cap = max(len(shard_indices(batch, world, r)) for r in range(world))
-    pad = torch.zeros((cap, L, 4, 4), dtype=local_poses.dtype, device=local_poses.device)
-    pad[: local_poses.shape[0]] = local_poses
+    pad = torch.zeros((cap, L, 4, 4), dtype=local_poses.dtype, device=xdev)
+    pad[: local_poses.shape[0]] = local_poses.to(xdev)
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return torch.cat([out[r][: len(shard_indices(batch, world, r))] for r in range(world)], 0)
+    return torch.cat([out[r][: len(shard_indices(batch, world, r))] for r in range(world)], 0).to(dev)
 
 
 def gather_ragged(rows: torch.Tensor) -> List[torch.Tensor]:
