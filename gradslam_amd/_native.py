@@ -31,7 +31,12 @@ SIGNATURES = {
     "gs_compact_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compact_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
     "gs_downsample_frame_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "gs_downsample_frame": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_downsample_frame": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_build_icp_target_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "gs_build_icp_target": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                  c_sz, c_p]),
+    "gs_bucket_by_pixel_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "gs_bucket_by_pixel": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_project_active_ws_bytes": (c_sz, [c_i, c_i]),
     "gs_project_active": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_gather_table_rows_ws_bytes": (c_sz, [c_i]),
@@ -47,10 +52,10 @@ SIGNATURES = {
     "gs_icp_linearize_backward": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "gs_transform_points": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
     "gs_icp_ws_bytes": (c_sz, [c_i, c_i]),
-    "gs_icp_point_to_plane": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_sz,
+    "gs_icp_point_to_plane": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_sz,
                                     c_p]),
     "gs_icp_point_to_plane_grad": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
-                                         c_p, c_p, c_p, c_p, c_sz, c_p]),
+                                         c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compose_poses": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "gs_slam_localize_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "gs_slam_localize": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f,

@@ -227,14 +227,58 @@ __device__ __forceinline__ void key_unpack(unsigned long long k, float &bd, int 
     bi = (k == KEY_NONE) ? 0x7fffffff : (int)(uint32_t)(k & 0xffffffffu);
 }
 
+// First association with pixel hints: every lane looks at the targets bucketed on the (2R+1)^2 ds-grid
+// pixels around its own pixel (scan order = pixel order, pix_start = first slot per pixel), the window
+// pixels shared over the waves.  A projective guess used as a SEED only: it hands the exact search a bound
+// that is already the true nearest distance for almost every lane.
+__device__ __forceinline__ void knn_window_seed(KnnShared &sh, const f3 s, const bool ok, const int i,
+                                                const gs_icp_hints &h, const int nt) {
+    constexpr int R = 2, WIN = (2 * R + 1) * (2 * R + 1), CAP = 4;  // at most CAP targets per window pixel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) sh.key[lane] = KEY_NONE;
+    __syncthreads();
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    const int npix = h.grid_w * h.grid_h;
+    const int p = ok ? min(max(h.src_pix[i], 0), npix - 1) : 0;
+    const int pr = p / h.grid_w, pc = p - pr * h.grid_w;
+    for (int wdx = wave; wdx < WIN; wdx += KNN_NW) {
+        const int rr = pr + wdx / (2 * R + 1) - R, cc = pc + wdx % (2 * R + 1) - R;
+        if (!ok || rr < 0 || rr >= h.grid_h || cc < 0 || cc >= h.grid_w) continue;
+        const int q0 = rr * h.grid_w + cc;
+        const int s0 = h.pix_start[q0], s1 = min(h.pix_start[q0 + 1], s0 + CAP);
+        for (int slot = s0; slot < s1; ++slot) {
+            const f3 q = ld3(h.scan_points, slot);
+            const int oj = h.scan_orig[slot];
+            const float d = dist2(s, q.x, q.y, q.z);
+            const bool better = (d < bd) | ((d == bd) & (oj < bi));
+            bd = better ? d : bd;
+            bi = better ? oj : bi;
+        }
+    }
+    if (wave == 0 && ok && bd == INFINITY) {  // empty window: the next target in pixel order is a valid seed
+        const int slot = min(max(h.pix_start[p], 0), nt - 1);
+        const f3 q = ld3(h.scan_points, slot);
+        bd = dist2(s, q.x, q.y, q.z);
+        bi = h.scan_orig[slot];
+    }
+    if (ok && bd < INFINITY) atomicMin(&sh.key[lane], pack_key(bd, bi));
+    __syncthreads();
+}
+
 // returns the packed key of lane's point (KEY_NONE when there is no target)
+// tgt      : target points in REFERENCE order (seeds are reference indices; so are the returned ones)
+// scan     : the same points in the order they are scanned (== tgt when scan_orig is NULL); boxes are
+//            built over this order
+// scan_orig: reference index of every scan slot, or NULL
 __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s, const bool ok, const int seed_j,
-                                                       const float *__restrict__ tgt, const float *__restrict__ boxes,
-                                                       const int nt) {
+                                                       const float *__restrict__ tgt, const float *__restrict__ scan,
+                                                       const int32_t *__restrict__ scan_orig,
+                                                       const float *__restrict__ boxes, const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     GS_STAMP(0);
     int n_scanned = 0;
-    if (wave == 0) {
+    if (wave == 0 && seed_j != -2) {  // -2: keys already seeded in LDS by knn_window_seed
         unsigned long long k0 = KEY_NONE;
         if (ok && seed_j >= 0) {
             const f3 q = ld3(tgt, seed_j);
@@ -249,7 +293,7 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
         if (lane == 0) sh.tbox[a] = r;
     }
     __syncthreads();
-    if (seed_j < 0) {
+    if (seed_j == -1) {
         // seed pass 1: a strided sample of KNN_COARSE target points, 16 per wave and step (uniform broadcast)
         const int M = min(nt, KNN_COARSE);
         const float stride = (float)nt / (float)M;
@@ -259,11 +303,13 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
             const int k = k0 + lane;
             const int n = min(16, M - k0);
             const int j = min((int)((float)k * stride), nt - 1);
-            const f3 q = (lane < n) ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
-            scan_held(s, q.x, q.y, q.z, j, n, bd, bi);
+            const f3 q = (lane < n) ? ld3(scan, j) : f3{0.0f, 0.0f, 0.0f};
+            const int oj = (scan_orig && lane < n) ? scan_orig[j] : j;
+            scan_held(s, q.x, q.y, q.z, oj, n, bd, bi);
         }
         if (ok && bd < INFINITY) atomicMin(&sh.key[lane], pack_key(bd, bi));
         __syncthreads();
+        if (scan_orig == nullptr) {
         // seed pass 2: clouds are image ordered, so index neighbours of the best sample are spatial
         // neighbours: each lane refines over [j*-R, j*+R) of ITS sample, the waves split the offsets
         constexpr int R = 64;
@@ -279,6 +325,7 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
         }
         if (ok && bi != jstar) atomicMin(&sh.key[lane], pack_key(bd, bi));
         __syncthreads();
+        }
     }
     GS_STAMP(1);
     // the tile's box (from LDS) and its loosest bound (same 64 points in every wave -> same value)
@@ -326,7 +373,8 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
             const int c = have ? sh.list[wave + KNN_NW * idx] : 0;
             const int j = c * CHUNK + (lane % CHUNK);
             const bool pv = have && j < nt;
-            const f3 q = pv ? ld3(tgt, j) : f3{0.0f, 0.0f, 0.0f};
+            const f3 q = pv ? ld3(scan, j) : f3{0.0f, 0.0f, 0.0f};
+            const int pj = pv ? (scan_orig ? scan_orig[j] : j) : 0x7fffffff;
             float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
             if (have) {
                 const float *b = boxes + 6 * (int64_t)c;
@@ -350,7 +398,7 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
                 const int bip = bi;
                 for (int k = 0; k < m; ++k) {
                     const float d = dist2(s, rlane(q.x, l0 + k), rlane(q.y, l0 + k), rlane(q.z, l0 + k));
-                    const int jj = cc * CHUNK + k;
+                    const int jj = __builtin_amdgcn_readlane(pj, l0 + k);
                     const bool better = (d < bd) | ((d == bd) & (jj < bi));
                     bd = better ? d : bd;
                     bi = better ? jj : bi;
@@ -396,7 +444,8 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
                                                       const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
                                                       const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
                                                       const float *__restrict__ nrm, float thresh,
-                                                      float *__restrict__ partials /* gridDim.x x NACC */) {
+                                                      float *__restrict__ partials /* gridDim.x x NACC */,
+                                                      gs_icp_hints hints) {
     __shared__ KnnShared sh;
     const int ns = *d_ns, nt = *d_nt;
     const int tile0 = blockIdx.x * 64;
@@ -429,7 +478,12 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
             sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
         }
     }
-    const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, boxes, nt);
+    const bool window_seed = first && hints.scan_points && hints.src_pix && hints.pix_start && hints.grid_w > 0;
+    if (window_seed) sj = -2;  // seeded by knn_window_seed below (block-uniform decision)
+    const float *scan = hints.scan_points ? hints.scan_points : tgt;
+    const int32_t *scan_orig = hints.scan_points ? hints.scan_orig : nullptr;
+    if (window_seed) knn_window_seed(sh, s, ok, i, hints, nt);
+    const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, scan, scan_orig, boxes, nt);
     // linearise this tile straight away (J fused into K's epilogue): 29 sums over the tile's 64 points,
     // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
     if (wave == 0) {
@@ -472,7 +526,7 @@ __global__ __launch_bounds__(KNN_BT) void knn1_box_k(const float *__restrict__ s
         if (ok && wave == 0) best[i] = KEY_NONE;
         return;
     }
-    const unsigned long long key = knn_tile(sh, s, ok, -1, tgt, boxes, nt);
+    const unsigned long long key = knn_tile(sh, s, ok, -1, tgt, tgt, nullptr, boxes, nt);
     if (ok && wave == 0) best[i] = key;
 }
 
@@ -946,8 +1000,11 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
 
 static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                    const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp, float thresh,
-                   GradParams gp, float *out_T, uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
-                   hipStream_t st, const char *name) {
+                   GradParams gp, const gs_icp_hints *hints_in, float *out_T, uint64_t *best_last, float *trace, void *ws,
+                   size_t ws_bytes, hipStream_t st, const char *name) {
+    gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (hints_in) hints = *hints_in;
+    GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
     GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && init_T && out_T, "%s: NULL argument", name);
     GS_REQUIRE(max_ns > 0 && max_nt > 0 && numiters >= 0, "%s: bad sizes max_ns=%d max_nt=%d numiters=%d", name, max_ns, max_nt, numiters);
     if (!ws || ws_bytes < icp_ws_layout(max_ns, max_nt, nullptr, nullptr)) {
@@ -965,12 +1022,13 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int fb = min(cdiv(max_ns, 256), 256);
 
     hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
-    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, tgt, d_nt, w.boxes);
+    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, hints.scan_points ? hints.scan_points : tgt, d_nt,
+                       w.boxes);
     GS_LAUNCH_CHECK(name);
     auto assoc = [&](int first) {
         prof_mark(0, 0, st);
         hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt, nrm, thresh,
-                           w.partials);
+                           w.partials, hints);
         prof_mark(0, 1, st);
     };
     auto step = [&](int mode) {
@@ -1145,22 +1203,22 @@ size_t gs_icp_ws_bytes(int max_ns, int max_nt) {
 
 int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
                           const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp,
-                          float dist_thresh, float *out_T, uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
-                          gs_stream_t stream) {
+                          float dist_thresh, const gs_icp_hints *hints, float *out_T, uint64_t *best_last, float *trace,
+                          void *ws, size_t ws_bytes, gs_stream_t stream) {
     return icp_run(false, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, damp, dist_thresh,
-                   GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f}, out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream,
-                   "gs_icp_point_to_plane");
+                   GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f}, hints, out_T, best_last, trace, ws, ws_bytes,
+                   (hipStream_t)stream, "gs_icp_point_to_plane");
 }
 
 int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
                                const float *tgt_normals, const int32_t *d_nt, int max_nt, const float *init_T,
                                int numiters, float damp, float dist_thresh, float lambda_max, float B, float B2, float nu,
-                               float *out_T, uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
-                               gs_stream_t stream) {
+                               const gs_icp_hints *hints, float *out_T, uint64_t *best_last, float *trace, void *ws,
+                               size_t ws_bytes, gs_stream_t stream) {
     return icp_run(true, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, damp, dist_thresh,
                    GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max), B, B2,
                               (float)(1.0 / (double)nu)},
-                   out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream, "gs_icp_point_to_plane_grad");
+                   hints, out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream, "gs_icp_point_to_plane_grad");
 }
 
 }  // extern "C"

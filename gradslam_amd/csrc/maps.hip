@@ -334,10 +334,12 @@ struct DsPred {
 struct DsWriter {
     const float *gv, *gn, *rgb;
     float *op, *on, *oc;
+    int32_t *opix;
     int W, Wd, ds;
     __device__ void operator()(int64_t i, int64_t pos) const {
         const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
         const int64_t pix = (int64_t)(r * ds) * W + c * ds;
+        if (opix) opix[pos] = (int32_t)i;  // ds-grid pixel id r * Wd + c
         if (op) st3(op, pos, ld3(gv, pix));
         if (on) st3(on, pos, ld3(gn, pix));
         if (oc) st3(oc, pos, ld3(rgb, pix));
@@ -488,7 +490,7 @@ size_t gs_downsample_frame_ws_bytes(int H, int W, int ds) {
 
 int gs_downsample_frame(const float *depth, const float *gvertex, const float *gnormal, const float *rgb, int B, int H,
                         int W, int ds, int cap, float *out_points, float *out_normals, float *out_colors,
-                        int32_t *counts, void *ws, size_t ws_bytes, gs_stream_t stream) {
+                        int32_t *out_pix, int32_t *counts, void *ws, size_t ws_bytes, gs_stream_t stream) {
     GS_REQUIRE(depth && counts && B > 0 && H > 0 && W > 0 && ds > 0, "gs_downsample_frame: bad arguments");
     const int Hd = cdiv(H, ds), Wd = cdiv(W, ds);
     GS_REQUIRE(cap >= Hd * Wd, "gs_downsample_frame: cap (%d) < ceil(H/ds)*ceil(W/ds) (%d)", cap, Hd * Wd);
@@ -505,7 +507,8 @@ int gs_downsample_frame(const float *depth, const float *gvertex, const float *g
                     rgb ? rgb + 3 * b * HW : nullptr,
                     out_points ? out_points + 3 * (int64_t)b * cap : nullptr,
                     out_normals ? out_normals + 3 * (int64_t)b * cap : nullptr,
-                    out_colors ? out_colors + 3 * (int64_t)b * cap : nullptr, W, Wd, ds};
+                    out_colors ? out_colors + 3 * (int64_t)b * cap : nullptr,
+                    out_pix ? out_pix + (int64_t)b * cap : nullptr, W, Wd, ds};
         int rc = compact_launch((int64_t)Hd * Wd, pred, wr, counts + b, ws, (hipStream_t)stream, "gs_downsample_frame");
         if (rc != GS_OK) return rc;
     }

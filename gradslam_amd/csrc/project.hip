@@ -125,6 +125,84 @@ __global__ void table_ds_mask_k(const int64_t *__restrict__ rows, int64_t n, int
         mask[i] = ((rows[4 * i + 2] % ds) == 0 && (rows[4 * i + 3] % ds) == 0) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------- target cloud in pixel order
+// The ICP target (map points on the ds-grid of the previous frame) arrives in MAP order, which stops
+// being spatially coherent once the map holds points of many frames.  Bucketing the rows by their
+// ds-grid pixel gives a scan order in which consecutive points are image neighbours again (tight AABBs
+// for the nearest-neighbour pruning) and, per pixel, one target index to seed the first association
+// with (a projective guess used only as a SEED: the search stays exact).  Indices reported to the caller
+// stay in the reference's order through `orig`.
+__global__ void pix_count_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
+                            const int32_t *__restrict__ starts, int Wd, int npix, int ds, int *__restrict__ cnt) {
+    const int n = *d_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const int b = (int)r.x;
+        const int pix = (int)(r.z / ds) * Wd + (int)(r.w / ds);
+        atomicAdd(cnt + (int64_t)b * npix + pix, 1);
+    }
+}
+// one block per batch element: exclusive scan of the pixel counts -> start[0..npix] (start[npix] = total).
+// Each thread owns a contiguous run of bins, so the block-level part is ONE scan of 1024 partials.
+__global__ __launch_bounds__(1024) void pix_scan_k(const int *__restrict__ cnt, int npix, int *__restrict__ start) {
+    __shared__ int sm[1024 / 64 + 1];
+    const int b = blockIdx.x;
+    cnt += (int64_t)b * npix; start += (int64_t)b * (npix + 1);
+    const int per = (npix + 1023) / 1024;
+    const int i0 = min(npix, (int)threadIdx.x * per), i1 = min(npix, i0 + per);
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += cnt[i];
+    int total;
+    int run = block_excl_scan<1024>(sum, sm, &total);
+    for (int i = i0; i < i1; ++i) { start[i] = run; run += cnt[i]; }
+    if (threadIdx.x == 0) start[npix] = total;
+}
+__global__ void pix_scatter_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
+                              const int32_t *__restrict__ starts, int Wd, int npix, int ds,
+                              const int *__restrict__ start, int *__restrict__ fill, const float *__restrict__ map_points,
+                              int Nmax, int cap, float *__restrict__ scan_pts, int32_t *__restrict__ scan_orig) {
+    const int n = *d_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const int b = (int)r.x;
+        const int pix = (int)(r.z / ds) * Wd + (int)(r.w / ds);
+        const int slot = start[(int64_t)b * (npix + 1) + pix] + atomicAdd(fill + (int64_t)b * npix + pix, 1);
+        if (slot >= cap) continue;
+        st3(scan_pts, (int64_t)b * cap + slot, ld3(map_points, (int64_t)b * Nmax + r.y));
+        scan_orig[(int64_t)b * cap + slot] = (int32_t)(i - starts[b]);
+    }
+}
+// fused front of the ICP target build: reference-order gather of points + normals AND the per-pixel
+// histogram / seed in one pass over the table rows
+__global__ void tgt_init_k(int *__restrict__ cnt, int *__restrict__ fill, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cnt[i] = 0; fill[i] = 0;
+    }
+}
+__global__ void tgt_gather_count_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
+                                   const int32_t *__restrict__ starts, const float *__restrict__ map_points,
+                                   const float *__restrict__ map_normals, int B, int Nmax, int cap,
+                                   float *__restrict__ tgt, float *__restrict__ tnrm, int32_t *__restrict__ counts, int Wd,
+                                   int npix, int ds, int *__restrict__ cnt) {
+    const int n = *d_n;
+    if (blockIdx.x == 0 && threadIdx.x < B) counts[threadIdx.x] = starts[threadIdx.x + 1] - starts[threadIdx.x];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const int b = (int)r.x;
+        const int k = (int)(i - starts[b]);
+        const int pix = (int)(r.z / ds) * Wd + (int)(r.w / ds);
+        atomicAdd(cnt + (int64_t)b * npix + pix, 1);
+        if (k >= cap) continue;
+        const int64_t src = (int64_t)b * Nmax + r.y, dst = (int64_t)b * cap + k;
+        st3(tgt, dst, ld3(map_points, src));
+        st3(tnrm, dst, ld3(map_normals, src));
+    }
+}
+
+__global__ void fill_i32b_k(int *__restrict__ p, int64_t n, int v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -174,6 +252,70 @@ int gs_gather_table_rows(const int64_t *rows, const int32_t *d_n_rows, int64_t m
     hipLaunchKernelGGL(gather_table_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, attr, B, Nmax,
                        C, cap, out, counts);
     GS_LAUNCH_CHECK("gs_gather_table_rows");
+    return GS_OK;
+}
+
+size_t gs_bucket_by_pixel_ws_bytes(int B, int H, int W, int ds) {
+    const size_t npix = (size_t)cdiv(H, ds) * cdiv(W, ds);
+    return align_up(sizeof(int32_t) * (size_t)(B + 1), 256) + 2 * align_up((size_t)B * npix * 4, 256);
+}
+
+int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H, int W, int ds,
+                       const float *map_points, int Nmax, int cap, float *scan_points, int32_t *scan_orig,
+                       int32_t *pix_start, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && map_points && scan_points && scan_orig && pix_start, "gs_bucket_by_pixel: NULL argument");
+    GS_REQUIRE(B > 0 && B <= 256 && H > 0 && W > 0 && ds > 0 && Nmax > 0 && cap > 0 && max_rows >= 0, "gs_bucket_by_pixel: bad shape");
+    if (!ws || ws_bytes < gs_bucket_by_pixel_ws_bytes(B, H, W, ds)) {
+        set_error("gs_bucket_by_pixel: workspace too small");
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int Wd = cdiv(W, ds), npix = cdiv(H, ds) * Wd;
+    char *p = (char *)ws;
+    int32_t *starts = (int32_t *)p; p += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+    const size_t seg = align_up((size_t)B * npix * 4, 256);
+    int *cnt = (int *)p, *fill = (int *)(p + seg);
+    const int64_t nbins = (int64_t)B * npix;
+    hipLaunchKernelGGL(tgt_init_k, dim3(min(cdiv(nbins, 256), 1024)), dim3(256), 0, st, cnt, fill, nbins);
+    hipLaunchKernelGGL(table_starts_k, dim3(cdiv(B + 1, 64)), dim3(64), 0, st, rows, d_n_rows, B, starts);
+    const int nb = max_rows > 0 ? min(cdiv(max_rows, 256), 1024) : 1;
+    hipLaunchKernelGGL(pix_count_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, cnt);
+    hipLaunchKernelGGL(pix_scan_k, dim3(B), dim3(1024), 0, st, cnt, npix, pix_start);
+    hipLaunchKernelGGL(pix_scatter_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, pix_start, fill, map_points,
+                       Nmax, cap, scan_points, scan_orig);
+    GS_LAUNCH_CHECK("gs_bucket_by_pixel");
+    return GS_OK;
+}
+
+size_t gs_build_icp_target_ws_bytes(int B, int H, int W, int ds) { return gs_bucket_by_pixel_ws_bytes(B, H, W, ds); }
+
+int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H, int W, int ds,
+                        const float *map_points, const float *map_normals, int Nmax, int cap, float *tgt, float *tgt_normals,
+                        int32_t *counts, float *scan_points, int32_t *scan_orig, int32_t *pix_start, void *ws,
+                        size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && map_points && map_normals && tgt && tgt_normals && counts && scan_points && scan_orig && pix_start,
+               "gs_build_icp_target: NULL argument");
+    GS_REQUIRE(B > 0 && B <= 256 && H > 0 && W > 0 && ds > 0 && Nmax > 0 && cap > 0 && max_rows >= 0, "gs_build_icp_target: bad shape");
+    if (!ws || ws_bytes < gs_build_icp_target_ws_bytes(B, H, W, ds)) {
+        set_error("gs_build_icp_target: workspace too small");
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int Wd = cdiv(W, ds), npix = cdiv(H, ds) * Wd;
+    char *p = (char *)ws;
+    int32_t *starts = (int32_t *)p; p += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+    const size_t seg = align_up((size_t)B * npix * 4, 256);
+    int *cnt = (int *)p, *fill = (int *)(p + seg);
+    const int64_t nbins = (int64_t)B * npix;
+    hipLaunchKernelGGL(tgt_init_k, dim3(min(cdiv(nbins, 256), 1024)), dim3(256), 0, st, cnt, fill, nbins);
+    hipLaunchKernelGGL(table_starts_k, dim3(cdiv(B + 1, 64)), dim3(64), 0, st, rows, d_n_rows, B, starts);
+    const int nb = max_rows > 0 ? min(cdiv(max_rows, 256), 1024) : 1;
+    hipLaunchKernelGGL(tgt_gather_count_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, map_points, map_normals, B, Nmax,
+                       cap, tgt, tgt_normals, counts, Wd, npix, ds, cnt);
+    hipLaunchKernelGGL(pix_scan_k, dim3(B), dim3(1024), 0, st, cnt, npix, pix_start);
+    hipLaunchKernelGGL(pix_scatter_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, pix_start, fill, map_points,
+                       Nmax, cap, scan_points, scan_orig);
+    GS_LAUNCH_CHECK("gs_build_icp_target");
     return GS_OK;
 }
 

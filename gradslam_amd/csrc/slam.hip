@@ -26,6 +26,10 @@ __global__ void eye4_k(float *__restrict__ T, int B) {
 
 struct LocWs {
     float *src;        // (B, capS, 3)
+    int32_t *src_pix;  // (B, capS) ds-grid pixel of every source point
+    float *scan;       // (B, capT, 3) target points in pixel order
+    int32_t *scan_orig;// (B, capT)
+    int32_t *pix_start;// (B, capS + 1) first scan slot of every ds-grid pixel
     int32_t *ns;       // (B)
     int64_t *rows;     // (B*Nmax, 4)
     int32_t *nrows;    // (1)
@@ -42,17 +46,22 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t o_src = take((size_t)B * capS * 12), o_ns = take((size_t)B * 4);
+    const size_t o_spix = take((size_t)B * capS * 4), o_scan = take((size_t)B * capT * 12);
+    const size_t o_sorig = take((size_t)B * capT * 4), o_pseed = take((size_t)B * (capS + 1) * 4);
     const size_t o_rows = take((size_t)B * Nmax * 32), o_nrows = take(4);
     const size_t o_tgt = take((size_t)B * capT * 12), o_tnrm = take((size_t)B * capT * 12), o_nt = take((size_t)B * 4);
     const size_t o_T = take((size_t)B * 64), o_eye = take((size_t)B * 64);
     size_t sub = gs_downsample_frame_ws_bytes(H, W, ds);
     sub = std::max(sub, gs_project_active_ws_bytes(B, Nmax));
     sub = std::max(sub, gs_gather_table_rows_ws_bytes(B));
+    sub = std::max(sub, gs_bucket_by_pixel_ws_bytes(B, H, W, ds));
     sub = std::max(sub, gs_icp_ws_bytes(capS, capT));
     const size_t o_sub = take(sub);
     if (ws && out) {
         char *p = (char *)ws;
         out->src = (float *)(p + o_src); out->ns = (int32_t *)(p + o_ns);
+        out->src_pix = (int32_t *)(p + o_spix); out->scan = (float *)(p + o_scan);
+        out->scan_orig = (int32_t *)(p + o_sorig); out->pix_start = (int32_t *)(p + o_pseed);
         out->rows = (int64_t *)(p + o_rows); out->nrows = (int32_t *)(p + o_nrows);
         out->tgt = (float *)(p + o_tgt); out->tnrm = (float *)(p + o_tnrm); out->nt = (int32_t *)(p + o_nt);
         out->T = (float *)(p + o_T); out->eye = (float *)(p + o_eye);
@@ -98,27 +107,29 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     int rc;
     // live frame posed with the previous pose: maps, then the ds-grid source cloud
     if ((rc = gs_vertex_normal_maps(depth, intrinsics, prev_poses, B, 1, H, W, vertex, normal, gvertex, gnormal, stream))) return rc;
-    if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.ns, w.sub,
-                                  w.sub_bytes, stream))) return rc;
+    if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.src_pix, w.ns,
+                                  w.sub, w.sub_bytes, stream))) return rc;
     // map points that land on the ds-grid of the previous frame: the ICP target
     if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
                                 w.sub_bytes, stream))) return rc;
-    if ((rc = gs_gather_table_rows(w.rows, w.nrows, (int64_t)B * Nmax, map_points, B, Nmax, 3, capT, w.tgt, w.nt, w.sub,
-                                   w.sub_bytes, stream))) return rc;
-    if ((rc = gs_gather_table_rows(w.rows, w.nrows, (int64_t)B * Nmax, map_normals, B, Nmax, 3, capT, w.tnrm, w.nt, w.sub,
-                                   w.sub_bytes, stream))) return rc;
+    // reference-order target (points, normals, counts) + the same points in pixel order and one seed
+    // per ds-grid pixel (search hints only)
+    if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
+                                  w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, w.sub, w.sub_bytes, stream))) return rc;
     hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
     GS_LAUNCH_CHECK("gs_slam_localize/eye");
     for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
         const float *src = w.src + (size_t)b * capS * 3;
         const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
+        const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
+                                 w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
         if (use_grad_lm)
             rc = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
-                                            dist_thresh, lambda_max, Bp, B2, nu, w.T + 16 * b, nullptr, nullptr, w.sub,
+                                            dist_thresh, lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, nullptr, nullptr, w.sub,
                                             w.sub_bytes, stream);
         else
             rc = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
-                                       dist_thresh, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, stream);
+                                       dist_thresh, &hints, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, stream);
         if (rc) return rc;
     }
     return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);

@@ -180,7 +180,7 @@ def downsample_frame_raw(depth, gV, gN, rgb, ds: int):
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
     ws = workspace(ws_bytes("gs_downsample_frame_ws_bytes", H, W, ds), dev, "compact")
     call("gs_downsample_frame", ptr(depth), ptr(gV), ptr(gN), ptr(rgb), B, H, W, ds, cap, ptr(op), ptr(on), ptr(oc),
-         ptr(counts), ptr(ws), ws.numel(), stream())
+         None, ptr(counts), ptr(ws), ws.numel(), stream())
     return op, on, oc, counts
 
 
@@ -365,11 +365,11 @@ def icp_device_loop(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_par
     d_ns, d_nt = dev_int(ns, dev), dev_int(nt, dev)
     if grad_params is None:
         call("gs_icp_point_to_plane", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),
-             int(numiters), float(damp), _thresh(dist_thresh), ptr(T), ptr(best), ptr(trace), ptr(ws), ws.numel(), stream())
+             int(numiters), float(damp), _thresh(dist_thresh), None, ptr(T), ptr(best), ptr(trace), ptr(ws), ws.numel(), stream())
     else:
         lmax, Bp, B2, nu = grad_params
         call("gs_icp_point_to_plane_grad", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),
-             int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp), float(B2), float(nu), ptr(T),
+             int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp), float(B2), float(nu), None, ptr(T),
              ptr(best), ptr(trace), ptr(ws), ws.numel(), stream())
     return T, best, trace
 

@@ -89,7 +89,8 @@ int gs_compact_multi(int n_arrays, const float *const *h_src, const int *h_row_f
 size_t gs_downsample_frame_ws_bytes(int H, int W, int ds);
 int gs_downsample_frame(const float *depth, const float *gvertex, const float *gnormal,
                         const float *rgb, int B, int H, int W, int ds, int cap, float *out_points,
-                        float *out_normals, float *out_colors, int32_t *counts, void *ws,
+                        float *out_normals, float *out_colors, int32_t *out_pix /* (B,cap) ds-grid pixel
+                        id r*ceil(W/ds)+c of every kept row, or NULL */, int32_t *counts, void *ws,
                         size_t ws_bytes, gs_stream_t stream);
 
 /* ---------------------------------------------------------------- P: active map points
@@ -111,6 +112,28 @@ size_t gs_gather_table_rows_ws_bytes(int B);
 int gs_gather_table_rows(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
                          const float *attr, int B, int Nmax, int C, int cap, float *out,
                          int32_t *counts, void *ws, size_t ws_bytes, gs_stream_t stream);
+
+/* Target cloud in pixel order: buckets the table rows (all on the ds-grid: gs_project_active with ds > 0)
+ * of each batch element by their ds-grid pixel.  scan_points (B,cap,3) = map points in pixel order,
+ * scan_orig (B,cap) = rank of each of them among the rows of its batch element (the index the reference's
+ * downsample_pointclouds order gives it), pix_start (B, npix+1 with npix = ceil(H/ds)*ceil(W/ds)) = first
+ * scan slot of every ds-grid pixel (pix_start[npix] = number of targets).  Feeds gs_icp_hints; changes no
+ * result, only the order in which the exact search visits the target. */
+size_t gs_bucket_by_pixel_ws_bytes(int B, int H, int W, int ds);
+int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H,
+                       int W, int ds, const float *map_points, int Nmax, int cap, float *scan_points,
+                       int32_t *scan_orig, int32_t *pix_start, void *ws, size_t ws_bytes,
+                       gs_stream_t stream);
+
+/* gs_gather_table_rows (points and normals) + gs_bucket_by_pixel fused into five launches: everything
+ * gs_icp_point_to_plane needs of its target -- tgt / tgt_normals (B,cap,3) and counts (B) in the reference's
+ * order, plus the search hints. */
+size_t gs_build_icp_target_ws_bytes(int B, int H, int W, int ds);
+int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H,
+                        int W, int ds, const float *map_points, const float *map_normals, int Nmax,
+                        int cap, float *tgt, float *tgt_normals, int32_t *counts, float *scan_points,
+                        int32_t *scan_orig, int32_t *pix_start, void *ws, size_t ws_bytes,
+                        gs_stream_t stream);
 
 /* keep mask of downsample_pointclouds' row filter for an arbitrary table
  * (odometry/icputils.py:596-597): mask[i] = rows[i].h % ds == 0 && rows[i].w % ds == 0 */
@@ -170,20 +193,33 @@ int gs_transform_points(const float *pts, const int32_t *d_n, int max_n, const f
  * on the device.  src (ns,3), tgt/normals (nt,3), init_T (device 4x4).  Outputs: T (device 4x4),
  * optional best_last (packed NN of the last iteration's first solve) and optional trace
  * (numiters x 48 floats: H36|g6|err|new_err|damp|accept|cnt|pad).  dist_thresh < 0 == None. */
+/* Optional search hints (NULL, or any member NULL, = none).  They never change a result: the
+ * association stays the exact nearest neighbour with the reference's tie-break, indices are reported in
+ * the reference order of `tgt`. */
+typedef struct gs_icp_hints {
+    const float *scan_points;   /* (nt,3) the target points in a spatially coherent scan order */
+    const int32_t *scan_orig;   /* (nt) reference index (into tgt) of every scan slot; required with scan_points */
+    const int32_t *src_pix;     /* (ns) ds-grid pixel id r*grid_w+c of every source point */
+    const int32_t *pix_start;   /* (grid_h*grid_w+1) first scan slot of every pixel (scan order = pixel order):
+                                   the FIRST association seeds every source point with the best target of the
+                                   pixels around its own (a projective guess, used as a seed only) */
+    int32_t grid_w, grid_h;
+} gs_icp_hints;
+
 size_t gs_icp_ws_bytes(int max_ns, int max_nt);
 int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
                           const float *tgt_normals, const int32_t *d_nt, int max_nt,
                           const float *init_T, int numiters, float damp, float dist_thresh,
-                          float *out_T, uint64_t *best_last, float *trace, void *ws,
-                          size_t ws_bytes, gs_stream_t stream);
+                          const gs_icp_hints *hints, float *out_T, uint64_t *best_last,
+                          float *trace, void *ws, size_t ws_bytes, gs_stream_t stream);
 
 /* point_to_plane_gradICP (odometry/icputils.py:479-545): the smooth gradLM variant. */
 int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
                                const float *tgt_normals, const int32_t *d_nt, int max_nt,
                                const float *init_T, int numiters, float damp, float dist_thresh,
-                               float lambda_max, float B, float B2, float nu, float *out_T,
-                               uint64_t *best_last, float *trace, void *ws, size_t ws_bytes,
-                               gs_stream_t stream);
+                               float lambda_max, float B, float B2, float nu,
+                               const gs_icp_hints *hints, float *out_T, uint64_t *best_last,
+                               float *trace, void *ws, size_t ws_bytes, gs_stream_t stream);
 
 /* ---------------------------------------------------------------- whole localisation step
  * ICPSLAM._localize for odom in {icp, gradicp} (slam/icpslam.py:238-247) as ONE call with no host
