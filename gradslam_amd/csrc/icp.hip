@@ -972,6 +972,8 @@ static inline void prof_mark(int tag, int which, hipStream_t st) {
     if (which == 1) g_prof.used[tag] = i + 1;
 }
 
+bool profiling_enabled() { return g_prof.on; }
+
 struct IcpWs {
     IcpState *S;
     LoopBufs B;

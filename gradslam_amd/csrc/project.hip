@@ -143,19 +143,34 @@ __global__ void pix_count_k(const int64_t *__restrict__ rows, const int32_t *__r
     }
 }
 // one block per batch element: exclusive scan of the pixel counts -> start[0..npix] (start[npix] = total).
-// Each thread owns a contiguous run of bins, so the block-level part is ONE scan of 1024 partials.
+// Bins are staged through LDS in tiles (coalesced loads / stores); inside a tile every thread owns a
+// contiguous run, so the block-level part is ONE scan of 1024 partials per tile.
+constexpr int PIX_TILE = 24 * 1024;  // bins per LDS tile (96 KiB)
 __global__ __launch_bounds__(1024) void pix_scan_k(const int *__restrict__ cnt, int npix, int *__restrict__ start) {
     __shared__ int sm[1024 / 64 + 1];
+    __shared__ int bins[PIX_TILE];
+    __shared__ int carry;
     const int b = blockIdx.x;
     cnt += (int64_t)b * npix; start += (int64_t)b * (npix + 1);
-    const int per = (npix + 1023) / 1024;
-    const int i0 = min(npix, (int)threadIdx.x * per), i1 = min(npix, i0 + per);
-    int sum = 0;
-    for (int i = i0; i < i1; ++i) sum += cnt[i];
-    int total;
-    int run = block_excl_scan<1024>(sum, sm, &total);
-    for (int i = i0; i < i1; ++i) { start[i] = run; run += cnt[i]; }
-    if (threadIdx.x == 0) start[npix] = total;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < npix; t0 += PIX_TILE) {
+        const int nb = min(PIX_TILE, npix - t0);
+        for (int i = threadIdx.x; i < nb; i += 1024) bins[i] = cnt[t0 + i];
+        __syncthreads();
+        const int per = (nb + 1023) / 1024;
+        const int i0 = min(nb, (int)threadIdx.x * per), i1 = min(nb, i0 + per);
+        int sum = 0;
+        for (int i = i0; i < i1; ++i) sum += bins[i];
+        int total;
+        int run = carry + block_excl_scan<1024>(sum, sm, &total);
+        for (int i = i0; i < i1; ++i) { const int c = bins[i]; bins[i] = run; run += c; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 1024) start[t0 + i] = bins[i];
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[npix] = carry;
 }
 __global__ void pix_scatter_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
                               const int32_t *__restrict__ starts, int Wd, int npix, int ds,

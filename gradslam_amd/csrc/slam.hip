@@ -1,9 +1,47 @@
 // slam.hip -- whole-step drivers: chains of the kernels of this library with every data-dependent size
 // kept on the device, so one C call enqueues a complete ICPSLAM._localize (reference
 // slam/icpslam.py:238-247) without a single host round trip.
+#include <mutex>
+#include <stdlib.h>
+#include <vector>
+
 #include "gs_common.hpp"
 
 namespace gs {
+
+bool profiling_enabled();  // icp.hip
+
+// ------------------------------------------------------------------ hipGraph cache for the ICP loops
+// Every argument of the (grad)ICP loop launched by gs_slam_localize lives in the caller's workspace, so
+// for a given workspace address and configuration the ~35 launches are the same bytes every frame:
+// capture them once (on a private stream: the user's may be the legacy default stream, which cannot be
+// captured) and replay the instantiated graph on the user's stream.  Replay costs one launch on the host
+// instead of ~35, which is what keeps the step GPU-bound on slow hosts.  GS_NO_GRAPH=1 disables it.
+struct GraphKey {
+    void *ws;
+    int B, capS, capT, numiters, use_grad;
+    float damp, thresh, lmax, Bp, B2, nu;
+    bool operator==(const GraphKey &o) const {
+        return ws == o.ws && B == o.B && capS == o.capS && capT == o.capT && numiters == o.numiters && use_grad == o.use_grad &&
+               damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu;
+    }
+};
+struct GraphEntry {
+    GraphKey key;
+    int device;
+    hipGraphExec_t exec;
+    unsigned long long last_use;
+};
+static std::mutex g_graph_mu;
+static std::vector<GraphEntry> g_graphs;
+static std::vector<GraphKey> g_seen_once;  // a configuration is captured the second time it shows up
+static unsigned long long g_graph_clock = 0;
+static int g_graph_mode = -1;  // -1: from the environment, 0: off, 1: on
+static bool graphs_allowed() {
+    static const bool env_off = getenv("GS_NO_GRAPH") != nullptr;
+    const bool on = (g_graph_mode < 0) ? !env_off : (g_graph_mode != 0);
+    return on && !profiling_enabled();
+}
 
 // kornia.geometry.linalg.compose_transformations semantics (call site reference slam/icpslam.py:245-247):
 // R = R01 R12 ; t = R01 t12 + t01 ; bottom row [0,0,0,1].   out[b] = T[b] . P[b]
@@ -41,14 +79,24 @@ struct LocWs {
     size_t sub_bytes;
 };
 
+// target capacity: the map size rounded up to a power of two, so that the workspace layout (and with it the
+// captured graph of the ICP loops) stays the same while a map grows frame by frame
+static inline int target_cap(int Nmax) {
+    int c = 1024;
+    while (c < Nmax && c < (1 << 30)) c <<= 1;
+    return c;
+}
+
 static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs *out) {
-    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = Nmax;
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t o_src = take((size_t)B * capS * 12), o_ns = take((size_t)B * 4);
     const size_t o_spix = take((size_t)B * capS * 4), o_scan = take((size_t)B * capT * 12);
     const size_t o_sorig = take((size_t)B * capT * 4), o_pseed = take((size_t)B * (capS + 1) * 4);
-    const size_t o_rows = take((size_t)B * Nmax * 32), o_nrows = take(4);
+    // NB every size below depends on (B, H, W, ds, capT) only -- never on Nmax itself -- so that pointers baked
+    // into a captured graph stay valid while the map grows inside one capacity bucket
+    const size_t o_rows = take((size_t)B * capT * 32), o_nrows = take(4);
     const size_t o_tgt = take((size_t)B * capT * 12), o_tnrm = take((size_t)B * capT * 12), o_nt = take((size_t)B * 4);
     const size_t o_T = take((size_t)B * 64), o_eye = take((size_t)B * 64);
     size_t sub = gs_downsample_frame_ws_bytes(H, W, ds);
@@ -75,6 +123,8 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
 using namespace gs;
 
 extern "C" {
+
+void gs_set_graph_mode(int mode) { g_graph_mode = mode; }
 
 int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream) {
     GS_REQUIRE(T && P && out && B > 0, "gs_compose_poses: bad arguments");
@@ -103,7 +153,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     hipStream_t st = (hipStream_t)stream;
     LocWs w;
     loc_layout(B, H, W, ds, Nmax, ws, &w);
-    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = Nmax;
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
     int rc;
     // live frame posed with the previous pose: maps, then the ds-grid source cloud
     if ((rc = gs_vertex_normal_maps(depth, intrinsics, prev_poses, B, 1, H, W, vertex, normal, gvertex, gnormal, stream))) return rc;
@@ -118,20 +168,76 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
                                   w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, w.sub, w.sub_bytes, stream))) return rc;
     hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
     GS_LAUNCH_CHECK("gs_slam_localize/eye");
-    for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
-        const float *src = w.src + (size_t)b * capS * 3;
-        const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
-        const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
-                                 w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
-        if (use_grad_lm)
-            rc = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
-                                            dist_thresh, lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, nullptr, nullptr, w.sub,
-                                            w.sub_bytes, stream);
-        else
-            rc = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
-                                       dist_thresh, &hints, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, stream);
-        if (rc) return rc;
+    auto enqueue_loops = [&](gs_stream_t s) -> int {
+        for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
+            const float *src = w.src + (size_t)b * capS * 3;
+            const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
+            const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
+                                     w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
+            int r;
+            if (use_grad_lm)
+                r = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                                               dist_thresh, lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, nullptr, nullptr, w.sub,
+                                               w.sub_bytes, s);
+            else
+                r = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                                          dist_thresh, &hints, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, s);
+            if (r) return r;
+        }
+        return GS_OK;
+    };
+    bool launched = false;
+    if (graphs_allowed() && numiters > 0) {
+        std::lock_guard<std::mutex> lock(g_graph_mu);
+        int device = 0;
+        (void)hipGetDevice(&device);
+        const GraphKey key{ws, B, capS, capT, numiters, use_grad_lm, damp, dist_thresh, lambda_max, Bp, B2, nu};
+        GraphEntry *hit = nullptr;
+        for (auto &e : g_graphs)
+            if (e.device == device && e.key == key) hit = &e;
+        bool seen = false;
+        if (!hit) {
+            for (auto &k : g_seen_once) seen = seen || (k == key);
+            if (!seen) {
+                if (g_seen_once.size() >= 16) g_seen_once.erase(g_seen_once.begin());
+                g_seen_once.push_back(key);
+            }
+        }
+        if (!hit && seen) {
+            hipStream_t cs = nullptr;
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int r = enqueue_loops((gs_stream_t)cs);
+                const hipError_t e = hipStreamEndCapture(cs, &graph);
+                ok = (r == GS_OK) && e == hipSuccess && graph != nullptr;
+            }
+            ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (cs) (void)hipStreamDestroy(cs);
+            if (ok) {
+                if (g_graphs.size() >= 8) {  // evict the least recently used
+                    size_t v = 0;
+                    for (size_t i = 1; i < g_graphs.size(); ++i)
+                        if (g_graphs[i].last_use < g_graphs[v].last_use) v = i;
+                    (void)hipGraphExecDestroy(g_graphs[v].exec);
+                    g_graphs.erase(g_graphs.begin() + v);
+                }
+                g_graphs.push_back(GraphEntry{key, device, exec, 0});
+                hit = &g_graphs.back();
+            } else {
+                (void)hipGetLastError();  // fall back to eager launches below
+            }
+        }
+        if (hit) {
+            hit->last_use = ++g_graph_clock;
+            GS_HIP(hipGraphLaunch(hit->exec, st), "gs_slam_localize/graph");
+            launched = true;
+        }
     }
+    if (!launched && (rc = enqueue_loops(stream))) return rc;
     return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);
 }
 

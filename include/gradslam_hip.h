@@ -230,6 +230,10 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
  * element; prev_poses / out_poses are B x 16.  vertex / normal / gnormal (B,H,W,3) are optional outputs
  * (NULL to skip), gvertex is required scratch/output.  use_grad_lm selects the gradLM variant. */
 int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream);
+/* gs_slam_localize replays its ICP loops as a cached hipGraph once a configuration repeats (all loop
+ * arguments live in the caller's workspace).  mode: 1 on, 0 off (eager launches), -1 default (on unless the
+ * environment variable GS_NO_GRAPH is set).  Results are identical either way. */
+void gs_set_graph_mode(int mode);
 size_t gs_slam_localize_ws_bytes(int B, int H, int W, int ds, int Nmax);
 int gs_slam_localize(const float *depth, const float *intrinsics, const float *prev_poses, int B,
                      int H, int W, int ds, const float *map_points, const float *map_normals,

@@ -496,6 +496,24 @@ def test_fused_localize_equals_staged(gs, golden):
         assert torch.equal(fused, staged), odom
 
 
+def test_graph_replay_equals_eager_on_a_growing_map(gs):
+    """The cached hipGraph of the ICP loops bakes workspace pointers in: a sequence whose map grows every
+    frame (same capacity bucket, different sizes) must give the eager result bit for bit."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(1, 8, 120, 160, seed=5)
+    out = []
+    for mode in (0, 1):
+        gs._native.lib().gs_set_graph_mode(mode)
+        slam = gs.slam.PointFusion(odom="icp", dsratio=2, numiters=5, device=DEV)
+        with torch.no_grad():
+            pcs, poses = slam(gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV)))
+        out.append((poses.clone(), pcs.points_list[0].clone()))
+    gs._native.lib().gs_set_graph_mode(-1)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert rel_err(out[1][0].cpu(), P) < 5e-2  # and it is a sane trajectory
+
+
 # ------------------------------------------------------------------ BASELINE sizes: properties
 def test_full_size_properties(gs):
     """640x480: size-independent properties (the oracle would take minutes here)."""
