@@ -30,9 +30,12 @@ __global__ void similar_k(const int64_t *__restrict__ rows, const int32_t *__res
         md = fmaxf(md, dot);
     }
     if (max_dot) {
+        // the caller only warns when a dot product exceeds 1.001 (un-normalised normals): publish the
+        // maximum only when it is above 1, so that the usual case costs no same-address atomics at all
+        // (one per wave on one word serialises: ~80 us for a 1 M-row table)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) md = fmaxf(md, __shfl_xor(md, off, kWave));
-        if ((threadIdx.x & 63) == 0 && md > 0.0f) atomicMax(reinterpret_cast<int *>(max_dot), __float_as_int(md));
+        if ((threadIdx.x & 63) == 0 && md > 1.0f) atomicMax(reinterpret_cast<int *>(max_dot), __float_as_int(md));
     }
 }
 

@@ -252,7 +252,8 @@ int gs_profile_read(int tag, long *launches, double *total_ms);
 /* ---------------------------------------------------------------- C+U: fusion correspondences
  * find_similar_map_points (slam/fusionutils.py:381-401): keep[i] = |Vg(b,h,w) - p(b,n)| < dist_th
  * (Euclidean) && Ng(b,h,w).nrm(b,n) > dot_th for every table row; max_dot (device float, may be
- * NULL) receives the maximum dot product (the reference warns when it exceeds 1.001). */
+ * NULL) receives the maximum dot product when that exceeds 1 and 0 otherwise (the reference warns when
+ * it exceeds 1.001: un-normalised normals). */
 int gs_fusion_similar(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
                       const float *gvertex, const float *gnormal, int H, int W,
                       const float *map_points, const float *map_normals, int Nmax, float dist_th,
