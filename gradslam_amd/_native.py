@@ -56,6 +56,12 @@ SIGNATURES = {
                                     c_p]),
     "gs_icp_point_to_plane_grad": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
                                          c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_icp_tape_bytes": (c_sz, [c_i, c_i, c_i]),
+    "gs_icp_point_to_plane_taped": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f,
+                                          c_p, c_p, c_p, c_p, c_sz, c_p, c_sz, c_p]),
+    "gs_icp_backward_ws_bytes": (c_sz, [c_i]),
+    "gs_icp_point_to_plane_backward": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_p, c_sz,
+                                             c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compose_poses": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "gs_set_graph_mode": (None, [c_i]),
     "gs_slam_localize_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),

@@ -431,15 +431,21 @@ struct IcpState {
     int it;
 };
 
+// Clouds and nearest-neighbour arrays live in numbered slots.  The plain loops use two of each and
+// ping-pong; the taped loops (autograd) give every association launch a slot of its own, so the tape
+// IS the loop's working storage and nothing is copied.
 struct LoopBufs {
-    float *pts[2];
-    unsigned long long *best[2];
+    float *pts;                  // slot s at pts + s * pts_stride (floats)
+    unsigned long long *best;    // slot s at best + s * best_stride
+    int64_t pts_stride, best_stride;
+    __host__ __device__ float *P(int s) const { return pts + s * pts_stride; }
+    __host__ __device__ unsigned long long *N(int s) const { return best + s * best_stride; }
 };
 
 // Association launch of the loops: in = (first ? user source : pts[p_cur]) transformed by S->dT,
-// out = pts[1 - p_cur], NN -> best[1 - b_cur].  Seed: the current cloud's NN of the same source index
+// out = pts[out_slot], NN -> best[out_slot]  (out_slot < 0: the other one of the two ping-pong slots).  Seed: the current cloud's NN of the same source index
 // when there is one, else the sampled seed pass.
-__global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S, int first,
+__global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S, int first, int out_slot,
                                                       const float *__restrict__ user_src, LoopBufs B,
                                                       const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
                                                       const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
@@ -454,9 +460,9 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
         return;
     }
     const int p_cur = S->p_cur, b_cur = S->b_cur;
-    const float *in = first ? user_src : B.pts[p_cur];
-    float *out = B.pts[1 - p_cur];
-    unsigned long long *best = B.best[1 - b_cur];
+    const float *in = first ? user_src : B.P(p_cur);
+    float *out = B.P(out_slot >= 0 ? out_slot : 1 - p_cur);
+    unsigned long long *best = B.N(out_slot >= 0 ? out_slot : 1 - b_cur);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = tile0 + lane;
     const bool ok = i < ns;
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
     if (!first) {
         sj = 0;
         if (ok) {
-            const unsigned long long k = B.best[b_cur][i];
+            const unsigned long long k = B.N(b_cur)[i];
             sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
         }
     }
@@ -813,16 +819,25 @@ __device__ void mm4(const float *A, const float *B, float *C) {
 
 enum StepMode { STEP_ADOPT = 0, STEP_LM = 1, STEP_GRAD_B = 2 };
 
+// Tape record of one step (REC_WORDS floats): the IcpState BEFORE the step, then what the step saw.
+// The state after step j is the state before step j+1, so record j+1's head doubles as "after j".
+constexpr int REC_STATE = 0;     // sizeof(IcpState)/4 words
+constexpr int REC_LIN = 96;      // 44 floats: H|g|e|cnt of the cloud the preceding association wrote
+constexpr int REC_SLOT = 140;    // slot that association wrote
+constexpr int REC_MODE = 141;
+constexpr int REC_ACCEPT = 142;
+constexpr int REC_WORDS = 160;
+
 struct GradParams {
     // formed in double on the host like the reference's Python scalars, rounded once:
     // lambda_min = 1/lambda_max, range = lambda_max - lambda_min, inv_nu = 1/nu
     float lambda_min, range, B, B2, inv_nu;
 };
 
-__device__ __forceinline__ void adopt_look(IcpState *S, const float *lin) {
+__device__ __forceinline__ void adopt_look(IcpState *S, const float *lin, int look_slot) {
     for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
-    S->p_cur = 1 - S->p_cur;
-    S->b_cur = 1 - S->b_cur;
+    S->p_cur = look_slot >= 0 ? look_slot : 1 - S->p_cur;
+    S->b_cur = look_slot >= 0 ? look_slot : 1 - S->b_cur;
 }
 
 // Reduces the partials of the association + linearise launches that just ran and advances the LM /
@@ -832,12 +847,18 @@ __device__ __forceinline__ void adopt_look(IcpState *S, const float *lin) {
 //   STEP_LM    : look-ahead cloud: accept (adopt, damp/2, T = dT T) or reject (damp*2) -> solve ; dT
 //   STEP_GRAD_B: look-ahead error -> damp, sigma ; dT = exp(sigma xi) ; T = dT T ; look-ahead discarded
 __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams gp, float *__restrict__ trace,
-                            float *__restrict__ out_T) {
+                            float *__restrict__ out_T, int look_slot, float *__restrict__ rec) {
     float lin[44];
     expand44(acc, lin);
+    if (rec) {  // tape: what the look-ahead launch measured, where it wrote, what this step is
+        for (int i = 0; i < 44; ++i) rec[REC_LIN + i] = lin[i];
+        rec[REC_SLOT] = (float)look_slot;
+        rec[REC_MODE] = (float)mode;
+        rec[REC_ACCEPT] = (mode == STEP_LM) ? ((lin[42] < S->cur[42]) ? 1.0f : 0.0f) : 1.0f;
+    }
 
     if (mode == STEP_ADOPT) {
-        adopt_look(S, lin);
+        adopt_look(S, lin, look_slot);
         S->b_first = S->b_cur;
         solve6(S->cur, S->cur + 36, S->damp, S->xi);
         se3_exp_dev(S->xi, S->dT);
@@ -852,7 +873,7 @@ __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams 
         }
         S->b_first = S->b_cur;
         if (accept) {
-            adopt_look(S, lin);
+            adopt_look(S, lin, look_slot);
             S->damp = S->damp / 2.0f;
             mm4(S->dT, S->T, S->T);
         } else {
@@ -892,7 +913,8 @@ __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams 
 
 __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
                                                   int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
-                                                  float *__restrict__ out_T) {
+                                                  float *__restrict__ out_T, int look_slot,
+                                                  float *__restrict__ rec /* this step's tape record or NULL */) {
     __shared__ float acc[NACC];
     __shared__ IcpState st;  // work on an LDS copy: ~200 dependent accesses at LDS, not HBM, latency
     constexpr int kWords = sizeof(IcpState) / 4;
@@ -901,15 +923,20 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 #endif
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
     reduce_partials(partials, nblocks, acc);  // ends with a barrier: st and acc are visible
+    if (rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(&st)[threadIdx.x];
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[1] = wall_clock64();
 #endif
-    if (threadIdx.x == 0) step_update(&st, acc, mode, gp, trace, out_T);
+    if (threadIdx.x == 0) step_update(&st, acc, mode, gp, trace, out_T, look_slot, rec);
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[2] = wall_clock64();
 #endif
     __syncthreads();
-    if (threadIdx.x < kWords) reinterpret_cast<int *>(Sg)[threadIdx.x] = reinterpret_cast<const int *>(&st)[threadIdx.x];
+    if (threadIdx.x < kWords) {
+        const int v = reinterpret_cast<const int *>(&st)[threadIdx.x];
+        reinterpret_cast<int *>(Sg)[threadIdx.x] = v;
+        if (rec) reinterpret_cast<int *>(rec)[REC_WORDS + REC_STATE + threadIdx.x] = v;  // head of the next record = state after
+    }
 }
 
 __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, float damp) {
@@ -925,7 +952,7 @@ __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, 
 
 __global__ void copy_best_last_k(const IcpState *__restrict__ S, LoopBufs B, const int32_t *__restrict__ d_ns,
                                  unsigned long long *__restrict__ out) {
-    const unsigned long long *src = B.best[S->b_first];
+    const unsigned long long *src = B.N(S->b_first);
     const int ns = *d_ns;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) out[i] = src[i];
 }
@@ -991,19 +1018,45 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     if (ws && out) {
         char *p = (char *)ws;
         out->S = (IcpState *)(p + oS);
-        out->B.pts[0] = (float *)(p + oP0); out->B.pts[1] = (float *)(p + oP1);
-        out->B.best[0] = (unsigned long long *)(p + oB0);
-        out->B.best[1] = (unsigned long long *)(p + oB1);
+        out->B.pts = (float *)(p + oP0);
+        out->B.pts_stride = (int64_t)(oP1 - oP0) / 4;
+        out->B.best = (unsigned long long *)(p + oB0);
+        out->B.best_stride = (int64_t)(oB1 - oB0) / 8;
         out->partials = (float *)(p + oPart);
         out->boxes = (float *)(p + oBox);
     }
     return off;
 }
 
+// ------------------------------------------------------------------ tape (autograd)
+// [records: (steps + 1) x REC_WORDS floats][cloud slots][nearest-neighbour slots]; one slot per association
+// launch, one record per step launch.  LM: numiters + 1 of each; gradLM: 2 numiters of each.
+struct Tape {
+    float *rec;
+    LoopBufs B;
+    int nslots;
+};
+static inline int tape_launches(bool grad, int numiters) { return grad ? 2 * numiters : numiters + 1; }
+static inline size_t tape_layout(bool grad, int max_ns, int numiters, void *tape, Tape *out) {
+    const int n = tape_launches(grad, numiters > 0 ? numiters : 1);
+    const size_t rec_b = align_up((size_t)(n + 1) * REC_WORDS * 4, 256);
+    const size_t pts_b = align_up((size_t)max_ns * 12, 256), best_b = align_up((size_t)max_ns * 8, 256);
+    if (tape && out) {
+        char *p = (char *)tape;
+        out->rec = (float *)p;
+        out->B.pts = (float *)(p + rec_b);
+        out->B.pts_stride = (int64_t)pts_b / 4;
+        out->B.best = (unsigned long long *)(p + rec_b + (size_t)n * pts_b);
+        out->B.best_stride = (int64_t)best_b / 8;
+        out->nslots = n;
+    }
+    return rec_b + (size_t)n * (pts_b + best_b);
+}
+
 static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                    const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp, float thresh,
                    GradParams gp, const gs_icp_hints *hints_in, float *out_T, uint64_t *best_last, float *trace, void *ws,
-                   size_t ws_bytes, hipStream_t st, const char *name) {
+                   size_t ws_bytes, hipStream_t st, const char *name, void *tape = nullptr, size_t tape_bytes = 0) {
     gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
@@ -1019,6 +1072,16 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     }
     IcpWs w;
     icp_ws_layout(max_ns, max_nt, ws, &w);
+    Tape tp{nullptr, {}, 0};
+    if (tape) {
+        if (tape_bytes < tape_layout(grad, max_ns, numiters, nullptr, nullptr)) {
+            set_error("%s: tape too small (%zu < %zu)", name, tape_bytes, tape_layout(grad, max_ns, numiters, nullptr, nullptr));
+            return GS_ERR_WORKSPACE_TOO_SMALL;
+        }
+        tape_layout(grad, max_ns, numiters, tape, &tp);
+        w.B = tp.B;  // the tape is the loop's working storage
+    }
+    int n_assoc = 0, n_step = 0;
     const dim3 kgrid(cdiv(max_ns, 64));
     const int lb = (int)kgrid.x;  // one partial row per 64-point tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
@@ -1029,12 +1092,15 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     GS_LAUNCH_CHECK(name);
     auto assoc = [&](int first) {
         prof_mark(0, 0, st);
-        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, src, w.B, d_ns, tgt, w.boxes, d_nt, nrm, thresh,
-                           w.partials, hints);
+        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, tape ? n_assoc : -1, src, w.B, d_ns, tgt,
+                           w.boxes, d_nt, nrm, thresh, w.partials, hints);
+        ++n_assoc;
         prof_mark(0, 1, st);
     };
     auto step = [&](int mode) {
-        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T);
+        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T,
+                           tape ? n_assoc - 1 : -1, tape ? tp.rec + (size_t)n_step * REC_WORDS : nullptr);
+        ++n_step;
     };
     assoc(1);
     step(STEP_ADOPT);
@@ -1060,6 +1126,401 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         hipLaunchKernelGGL(copy_best_last_k, dim3(fb), dim3(256), 0, st, w.S, w.B, d_ns, (unsigned long long *)best_last);
         GS_LAUNCH_CHECK(name);
     }
+    return GS_OK;
+}
+
+
+// ------------------------------------------------------------------ reverse pass of the taped loops
+// Walks the tape backwards entirely on the device (accept/reject is read from the records, so rejected LM
+// iterations cost three empty launches and no host round trip).  Per iteration:
+//   A  sums_k   : sum_i gP_i (x) s_i , sum_i gP_i      (adjoint of  s' = dT s  with respect to dT)
+//   S  small_k  : adjoints of T' = dT T, dT = exp(xi), xi = (H + damp I)^-1 g, and of the gradLM gates
+//   B  look_k   : gradLM only -- adjoint of the look-ahead error
+//   C  lin_k    : gP_i <- R^T gP_i + adjoint of the linearisation (H, g, e) at s_i
+// gP (ns,3) is updated in place, target / normal adjoints accumulate with float atomics.
+constexpr int BWD_T = 256;
+constexpr int BWD_MAXB = 512;
+
+struct BwdState {
+    float gT[16];    // adjoint of the accumulated transform
+    float G[44];     // Hbar(36) | gbar(6) | ebar | pad : what lin_k applies
+    float gdT[12];   // adjoint of the top 3 rows of the step being unwound (row-major 3x4)
+    float R2[9];     // rotation by which lin_k pulls gP back (the step that produced the cloud gP belongs to)
+    float R1[9];     // gradLM: rotation of the look-ahead step
+    float gxi[6];
+    float g_new_err, g_err, gdamp;
+    int active;      // 0: rejected LM iteration, nothing to do
+    int src_slot, nn_slot, look_slot;
+};
+
+__device__ __forceinline__ const IcpState *rec_state(const float *rec) { return reinterpret_cast<const IcpState *>(rec + REC_STATE); }
+
+// adjoint of one linearised point: returns s_bar, scatters d_bar / n_bar
+__device__ __forceinline__ f3 lin_point_bwd(const float *G, const Row &r, const f3 s, const uint32_t j, const float *tgt,
+                                            const float *nrm, float *g_tgt, float *g_nrm) {
+    const f3 d = ld3(tgt, j), n = ld3(nrm, j);
+    float ab[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        float v = G[36 + u] * r.b;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) v += (G[6 * u + w] + G[6 * w + u]) * r.a[w];
+        ab[u] = v;
+    }
+    float bb = 2.0f * G[42] * r.b;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) bb += G[36 + u] * r.a[u];
+    const f3 an{ab[0], ab[1], ab[2]}, ac{ab[3], ab[4], ab[5]};
+    f3 sb{n.y * ac.z - n.z * ac.y, n.z * ac.x - n.x * ac.z, n.x * ac.y - n.y * ac.x};
+    f3 nb{an.x + (ac.y * s.z - ac.z * s.y), an.y + (ac.z * s.x - ac.x * s.z), an.z + (ac.x * s.y - ac.y * s.x)};
+    sb.x -= bb * n.x; sb.y -= bb * n.y; sb.z -= bb * n.z;
+    nb.x += bb * (d.x - s.x); nb.y += bb * (d.y - s.y); nb.z += bb * (d.z - s.z);
+    if (g_tgt) {
+        atomicAdd(g_tgt + 3 * (int64_t)j, bb * n.x);
+        atomicAdd(g_tgt + 3 * (int64_t)j + 1, bb * n.y);
+        atomicAdd(g_tgt + 3 * (int64_t)j + 2, bb * n.z);
+    }
+    if (g_nrm) {
+        atomicAdd(g_nrm + 3 * (int64_t)j, nb.x);
+        atomicAdd(g_nrm + 3 * (int64_t)j + 1, nb.y);
+        atomicAdd(g_nrm + 3 * (int64_t)j + 2, nb.z);
+    }
+    return sb;
+}
+
+// 12 running sums of a block -> partials[blockIdx.x][12] (fixed order: wave butterflies, then waves in order)
+__device__ __forceinline__ void block_store12(float *acc, float *__restrict__ partials) {
+    __shared__ float wsum[BWD_T / 64][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) wsum[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float v = 0.0f;
+        for (int w = 0; w < BWD_T / 64; ++w) v += wsum[w][threadIdx.x];
+        partials[blockIdx.x * 12 + threadIdx.x] = v;
+    }
+}
+__device__ __forceinline__ void acc_outer(float *acc, const f3 g, const f3 s) {
+    acc[0] += g.x * s.x; acc[1] += g.x * s.y; acc[2] += g.x * s.z; acc[3] += g.x;
+    acc[4] += g.y * s.x; acc[5] += g.y * s.y; acc[6] += g.y * s.z; acc[7] += g.y;
+    acc[8] += g.z * s.x; acc[9] += g.z * s.y; acc[10] += g.z * s.z; acc[11] += g.z;
+}
+__device__ __forceinline__ f3 rot_t(const float *R, const f3 g) {  // R^T g, R row-major 3x3
+    return f3{R[0] * g.x + R[3] * g.y + R[6] * g.z, R[1] * g.x + R[4] * g.y + R[7] * g.z, R[2] * g.x + R[5] * g.y + R[8] * g.z};
+}
+
+// A: adjoint of (cloud' = dT . cloud) with respect to dT, cloud = the iteration's source slot
+__global__ __launch_bounds__(BWD_T) void bwd_sums_k(const float *__restrict__ rec, LoopBufs B, const float *__restrict__ user_src,
+                                                    const int32_t *__restrict__ d_ns, const float *__restrict__ gP,
+                                                    float *__restrict__ partials) {
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    const bool active = rec ? rec[REC_ACCEPT] != 0.0f : true;
+    if (active) {
+        const float *src = rec ? B.P(rec_state(rec)->p_cur) : user_src;
+        const int ns = *d_ns;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) acc_outer(acc, ld3(gP, i), ld3(src, i));
+    }
+    block_store12(acc, partials);
+}
+
+// B (gradLM): adjoint of new_err = e(look, NN(look)); gP_i <- R2^T gP_i + R1^T glook_i ; sums glook (x) s
+__global__ __launch_bounds__(BWD_T) void bwd_look_k(const BwdState *__restrict__ Sb, LoopBufs B, const int32_t *__restrict__ d_ns,
+                                                    const float *__restrict__ tgt, const float *__restrict__ nrm, float thresh,
+                                                    float *__restrict__ gP, float *__restrict__ g_tgt, float *__restrict__ g_nrm,
+                                                    float *__restrict__ partials) {
+    __shared__ float G[44];
+    __shared__ float R[18];
+    if (threadIdx.x < 44) G[threadIdx.x] = (threadIdx.x == 42) ? Sb->g_new_err : 0.0f;
+    if (threadIdx.x >= 64 && threadIdx.x < 73) R[threadIdx.x - 64] = Sb->R2[threadIdx.x - 64];
+    if (threadIdx.x >= 128 && threadIdx.x < 137) R[9 + threadIdx.x - 128] = Sb->R1[threadIdx.x - 128];
+    __syncthreads();
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    const float *src = B.P(Sb->src_slot), *look = B.P(Sb->look_slot);
+    const unsigned long long *nn = B.N(Sb->look_slot);
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const Row r = make_row(look, tgt, nrm, nn, i, ns, thresh);
+        f3 gl{0.0f, 0.0f, 0.0f};
+        if (r.valid) gl = lin_point_bwd(G, r, ld3(look, i), (uint32_t)(nn[i] & 0xffffffffu), tgt, nrm, g_tgt, g_nrm);
+        acc_outer(acc, gl, ld3(src, i));
+        const f3 a = rot_t(R, ld3(gP, i)), b = rot_t(R + 9, gl);
+        st3(gP, i, f3{a.x + b.x, a.y + b.y, a.z + b.z});
+    }
+    block_store12(acc, partials);
+}
+
+// C: gP_i <- (rotate ? R2^T gP_i : gP_i) + adjoint of (H, g, e) at the iteration's source cloud
+__global__ __launch_bounds__(BWD_T) void bwd_lin_k(const BwdState *__restrict__ Sb, int rotate, LoopBufs B,
+                                                   const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                                                   const float *__restrict__ nrm, float thresh, float *__restrict__ gP,
+                                                   float *__restrict__ g_tgt, float *__restrict__ g_nrm) {
+    if (!Sb->active) return;
+    __shared__ float G[44];
+    __shared__ float R[9];
+    if (threadIdx.x < 44) G[threadIdx.x] = Sb->G[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 73) R[threadIdx.x - 64] = Sb->R2[threadIdx.x - 64];
+    __syncthreads();
+    const float *src = B.P(Sb->src_slot);
+    const unsigned long long *nn = B.N(Sb->nn_slot);
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const Row r = make_row(src, tgt, nrm, nn, i, ns, thresh);
+        f3 g = ld3(gP, i);
+        if (rotate) g = rot_t(R, g);
+        if (r.valid) {
+            const f3 sb = lin_point_bwd(G, r, ld3(src, i), (uint32_t)(nn[i] & 0xffffffffu), tgt, nrm, g_tgt, g_nrm);
+            g.x += sb.x; g.y += sb.y; g.z += sb.z;
+        }
+        st3(gP, i, g);
+    }
+}
+
+// last: through src0 = init_T . user_src
+__global__ __launch_bounds__(BWD_T) void bwd_finish_k(const float *__restrict__ init_T, const int32_t *__restrict__ d_ns,
+                                                      const float *__restrict__ gP, float *__restrict__ g_src) {
+    __shared__ float R[9];
+    if (threadIdx.x < 9) R[threadIdx.x] = init_T[4 * (threadIdx.x / 3) + threadIdx.x % 3];
+    __syncthreads();
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) st3(g_src, i, rot_t(R, ld3(gP, i)));
+}
+
+// ---- O(1) adjoints, fp64 on one lane
+// adjoint of T = se3_exp(xi) (se3_exp_dev above, both branches) given gT (top 3 rows, row-major 3x4)
+__device__ void se3_exp_bwd(const float *xi, const double *gT, double *gxi) {
+    const double v[3] = {xi[0], xi[1], xi[2]}, w[3] = {xi[3], xi[4], xi[5]};
+    const double Wh[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
+    const float thf = sqrtf(__fmaf_rn(xi[5], xi[5], __fmaf_rn(xi[4], xi[4], xi[3] * xi[3])));  // the branch the forward took
+    double gR[9], gV[9], gt[3] = {gT[3], gT[7], gT[11]};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { gR[3 * i + j] = gT[4 * i + j]; gV[3 * i + j] = gt[i] * v[j]; }
+    double V[9], gWh[9], gw[3] = {0.0, 0.0, 0.0};
+    if (thf < 1e-6f) {
+        for (int i = 0; i < 9; ++i) { V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Wh[i]; gWh[i] = gR[i] + gV[i]; }
+    } else {
+        const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double s = sin(th), c = cos(th);
+        double W2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) W2[3 * i + j] = Wh[3 * i] * Wh[j] + Wh[3 * i + 1] * Wh[3 + j] + Wh[3 * i + 2] * Wh[6 + j];
+        const double th2 = th * th, th3 = th2 * th, th4 = th2 * th2;
+        const double A = s / th, Bc = (1.0 - c) / th2, C = (th - s) / th3;
+        double gA = 0.0, gB = 0.0, gC = 0.0, gW2[9];
+        for (int i = 0; i < 9; ++i) {
+            V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Bc * Wh[i] + C * W2[i];
+            gA += gR[i] * Wh[i];
+            gB += gR[i] * W2[i] + gV[i] * Wh[i];
+            gC += gV[i] * W2[i];
+            gWh[i] = A * gR[i] + Bc * gV[i];
+            gW2[i] = Bc * gR[i] + C * gV[i];
+        }
+        for (int i = 0; i < 3; ++i)      // W2 = Wh Wh : gWh += gW2 Wh^T + Wh^T gW2
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < 3; ++k) a += gW2[3 * i + k] * Wh[3 * j + k] + Wh[3 * k + i] * gW2[3 * k + j];
+                gWh[3 * i + j] += a;
+            }
+        const double dA = (c * th - s) / th2, dB = (s * th - 2.0 * (1.0 - c)) / th3, dC = ((1.0 - c) * th - 3.0 * (th - s)) / th4;
+        const double gth = gA * dA + gB * dB + gC * dC;
+        for (int k = 0; k < 3; ++k) gw[k] = gth * w[k] / th;
+    }
+    gw[0] += gWh[7] - gWh[5];
+    gw[1] += gWh[2] - gWh[6];
+    gw[2] += gWh[3] - gWh[1];
+    for (int j = 0; j < 3; ++j) gxi[j] = V[j] * gt[0] + V[3 + j] * gt[1] + V[6 + j] * gt[2];  // V^T gt
+    gxi[3] = gw[0]; gxi[4] = gw[1]; gxi[5] = gw[2];
+}
+
+// sum of the 12-wide partial rows, one thread per sum (nblocks <= BWD_MAXB)
+__device__ __forceinline__ void reduce12(const float *__restrict__ partials, int nblocks, float *out_sm) {
+    if (threadIdx.x < 12) {
+        float v = 0.0f;
+        for (int b = 0; b < nblocks; ++b) v += partials[b * 12 + threadIdx.x];
+        out_sm[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void top3_times_Tt(const float *gTn, const float *T, double *out12) {  // (gTn . T^T) rows 0..2
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 4; ++k) a += (double)gTn[4 * i + k] * (double)T[4 * j + k];
+            out12[4 * i + j] = a;
+        }
+}
+__device__ __forceinline__ void pull_gT(float *gT, const float *dT) {  // gT <- dT^T gT
+    float r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 4; ++k) a += (double)dT[4 * k + i] * (double)gT[4 * k + j];
+            r[4 * i + j] = (float)a;
+        }
+    for (int i = 0; i < 16; ++i) gT[i] = r[i];
+}
+// xi = (H + damp I)^-1 g : given gxi -> G (Hbar, gbar), returns damp_bar
+__device__ double solve_bwd(const float *H, float damp, const float *xi, const double *gxi, float *G) {
+    float gx[6], y[6];
+    for (int i = 0; i < 6; ++i) gx[i] = (float)gxi[i];
+    solve6(H, gx, damp, y);  // M symmetric: M^-T = M^-1
+    double gd = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) G[6 * i + j] = -y[i] * xi[j];
+        G[36 + i] = y[i];
+        gd -= (double)y[i] * (double)xi[i];
+    }
+    return gd;
+}
+
+__global__ void bwd_init_k(BwdState *Sb, const float *__restrict__ grad_T) {
+    if (threadIdx.x < 16) Sb->gT[threadIdx.x] = grad_T[threadIdx.x];
+    if (threadIdx.x == 0) { Sb->gdamp = 0.0f; Sb->active = 0; }
+}
+
+// S for one LM iteration (record = the STEP_LM record of that iteration)
+__global__ __launch_bounds__(64) void bwd_small_lm_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
+                                                     int nblocks) {
+    __shared__ float sums[12];
+    reduce12(partials, nblocks, sums);
+    if (threadIdx.x != 0) return;
+    const IcpState *S = rec_state(rec);
+    if (rec[REC_ACCEPT] == 0.0f) { Sb->active = 0; return; }
+    double gdT[12], gxi[6];
+    top3_times_Tt(Sb->gT, S->T, gdT);
+    for (int k = 0; k < 12; ++k) gdT[k] += (double)sums[k];
+    pull_gT(Sb->gT, S->dT);
+    se3_exp_bwd(S->xi, gdT, gxi);
+    solve_bwd(S->cur, S->damp, S->xi, gxi, Sb->G);
+    Sb->G[42] = 0.0f; Sb->G[43] = 0.0f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Sb->R2[3 * i + j] = S->dT[4 * i + j];
+    Sb->src_slot = S->p_cur; Sb->nn_slot = S->b_cur; Sb->look_slot = (int)rec[REC_SLOT];
+    Sb->active = 1;
+}
+
+// S1 for one gradLM iteration (record = its STEP_GRAD_B record; the next record's head = the state after)
+__global__ __launch_bounds__(64) void bwd_small_g1_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
+                                                     int nblocks, GradParams gp) {
+    __shared__ float sums[12];
+    reduce12(partials, nblocks, sums);
+    if (threadIdx.x != 0) return;
+    const IcpState *S = rec_state(rec), *Sn = rec_state(rec + REC_WORDS);
+    const float err = S->cur[42], new_err = rec[REC_LIN + 42];
+    const float raw = new_err - err;
+    const float diff = fminf(fmaxf(raw, -70.0f), 70.0f);
+    const bool pass = raw >= -70.0f && raw <= 70.0f;  // clamp passes the adjoint inside the range (torch.clamp)
+    const double eB = exp(-(double)gp.B * diff), eB2 = exp(-(double)gp.B2 * diff);
+    const double F = (double)gp.lambda_min + (double)gp.range / (1.0 + eB);
+    const double dF = (double)gp.range * (double)gp.B * eB / ((1.0 + eB) * (1.0 + eB));
+    const double sig = pow(1.0 + eB2, -(double)gp.inv_nu);
+    const double dsig = (double)gp.inv_nu * (double)gp.B2 * eB2 * pow(1.0 + eB2, -(double)gp.inv_nu - 1.0);
+    float sx[6];
+    for (int i = 0; i < 6; ++i) sx[i] = (float)sig * S->xi[i];
+    double gdT2[12], gsx[6];
+    top3_times_Tt(Sb->gT, S->T, gdT2);
+    for (int k = 0; k < 12; ++k) gdT2[k] += (double)sums[k];
+    pull_gT(Sb->gT, Sn->dT);
+    se3_exp_bwd(sx, gdT2, gsx);
+    double g_s = 0.0;
+    for (int i = 0; i < 6; ++i) { g_s += gsx[i] * (double)S->xi[i]; Sb->gxi[i] = (float)(sig * gsx[i]); }
+    const double gdamp_next = Sb->gdamp;
+    const double g_diff = pass ? gdamp_next * (double)S->damp * dF + g_s * dsig : 0.0;
+    Sb->gdamp = (float)(gdamp_next * F);
+    Sb->g_new_err = (float)g_diff;
+    Sb->g_err = (float)(-g_diff);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { Sb->R2[3 * i + j] = Sn->dT[4 * i + j]; Sb->R1[3 * i + j] = S->dT[4 * i + j]; }
+    Sb->src_slot = S->p_cur; Sb->nn_slot = S->b_cur; Sb->look_slot = (int)rec[REC_SLOT];
+    Sb->active = 1;
+}
+
+// S2: look-ahead step dT1 = exp(xi) -> xi ; then the solve
+__global__ __launch_bounds__(64) void bwd_small_g2_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
+                                                     int nblocks) {
+    __shared__ float sums[12];
+    reduce12(partials, nblocks, sums);
+    if (threadIdx.x != 0) return;
+    const IcpState *S = rec_state(rec);
+    double gdT1[12], gxi[6];
+    for (int k = 0; k < 12; ++k) gdT1[k] = (double)sums[k];
+    se3_exp_bwd(S->xi, gdT1, gxi);
+    for (int i = 0; i < 6; ++i) gxi[i] += (double)Sb->gxi[i];
+    const double gd = solve_bwd(S->cur, S->damp, S->xi, gxi, Sb->G);
+    Sb->gdamp = (float)((double)Sb->gdamp + gd);
+    Sb->G[42] = Sb->g_err; Sb->G[43] = 0.0f;
+}
+
+// adjoint of init_T: the T chain starts at init_T and src0 = init_T . user_src
+__global__ __launch_bounds__(64) void bwd_small_end_k(const BwdState *Sb, const float *__restrict__ partials, int nblocks,
+                                                      float *__restrict__ g_init_T) {
+    __shared__ float sums[12];
+    reduce12(partials, nblocks, sums);
+    if (threadIdx.x < 16) g_init_T[threadIdx.x] = Sb->gT[threadIdx.x] + (threadIdx.x < 12 ? sums[threadIdx.x] : 0.0f);
+}
+
+struct BwdWs {
+    BwdState *S;
+    float *gP, *partials;
+};
+static inline size_t bwd_ws_layout(int max_ns, void *ws, BwdWs *out) {
+    const size_t oS = 0, oG = align_up(sizeof(BwdState), 256), oP = oG + align_up((size_t)max_ns * 12, 256);
+    if (ws && out) {
+        char *p = (char *)ws;
+        out->S = (BwdState *)(p + oS); out->gP = (float *)(p + oG); out->partials = (float *)(p + oP);
+    }
+    return oP + align_up((size_t)BWD_MAXB * 12 * 4, 256);
+}
+
+static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
+                            int max_nt, const float *init_T, int numiters, float thresh, GradParams gp, const void *tape,
+                            size_t tape_bytes, const float *grad_T, float *g_src, float *g_tgt, float *g_nrm, float *g_init_T,
+                            void *ws, size_t ws_bytes, hipStream_t st) {
+    const char *name = "gs_icp_backward";
+    GS_REQUIRE(src && d_ns && tgt && nrm && init_T && tape && grad_T && g_src && g_init_T, "%s: NULL argument", name);
+    GS_REQUIRE(max_ns > 0 && max_nt > 0 && numiters >= 0, "%s: bad sizes", name);
+    if (!ws || ws_bytes < bwd_ws_layout(max_ns, nullptr, nullptr)) {
+        set_error("%s: workspace too small", name);
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    GS_REQUIRE(tape_bytes >= tape_layout(grad, max_ns, numiters, nullptr, nullptr), "%s: tape too small", name);
+    Tape tp;
+    tape_layout(grad, max_ns, numiters, (void *)tape, &tp);
+    BwdWs w;
+    bwd_ws_layout(max_ns, ws, &w);
+    const int nb = min(cdiv(max_ns, BWD_T), BWD_MAXB);
+    GS_HIP(hipMemsetAsync(w.gP, 0, (size_t)max_ns * 12, st), name);
+    if (g_tgt) GS_HIP(hipMemsetAsync(g_tgt, 0, (size_t)max_nt * 12, st), name);
+    if (g_nrm) GS_HIP(hipMemsetAsync(g_nrm, 0, (size_t)max_nt * 12, st), name);
+    hipLaunchKernelGGL(bwd_init_k, dim3(1), dim3(64), 0, st, w.S, grad_T);
+    for (int k = numiters - 1; k >= 0; --k) {
+        if (!grad) {
+            const float *rec = tp.rec + (size_t)(1 + k) * REC_WORDS;
+            hipLaunchKernelGGL(bwd_sums_k, dim3(nb), dim3(BWD_T), 0, st, rec, tp.B, src, d_ns, w.gP, w.partials);
+            hipLaunchKernelGGL(bwd_small_lm_k, dim3(1), dim3(64), 0, st, w.S, rec, w.partials, nb);
+            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 1, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm);
+        } else {
+            const float *rec = tp.rec + (size_t)(1 + 2 * k) * REC_WORDS;
+            hipLaunchKernelGGL(bwd_sums_k, dim3(nb), dim3(BWD_T), 0, st, rec, tp.B, src, d_ns, w.gP, w.partials);
+            hipLaunchKernelGGL(bwd_small_g1_k, dim3(1), dim3(64), 0, st, w.S, rec, w.partials, nb, gp);
+            hipLaunchKernelGGL(bwd_look_k, dim3(nb), dim3(BWD_T), 0, st, w.S, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
+                               w.partials);
+            hipLaunchKernelGGL(bwd_small_g2_k, dim3(1), dim3(64), 0, st, w.S, rec, w.partials, nb);
+            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 0, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm);
+        }
+    }
+    hipLaunchKernelGGL(bwd_sums_k, dim3(nb), dim3(BWD_T), 0, st, (const float *)nullptr, tp.B, src, d_ns, w.gP, w.partials);
+    hipLaunchKernelGGL(bwd_small_end_k, dim3(1), dim3(64), 0, st, w.S, w.partials, nb, g_init_T);
+    hipLaunchKernelGGL(bwd_finish_k, dim3(nb), dim3(BWD_T), 0, st, init_T, d_ns, w.gP, g_src);
+    GS_LAUNCH_CHECK(name);
     return GS_OK;
 }
 
@@ -1221,6 +1682,48 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
                    GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max), B, B2,
                               (float)(1.0 / (double)nu)},
                    hints, out_T, best_last, trace, ws, ws_bytes, (hipStream_t)stream, "gs_icp_point_to_plane_grad");
+}
+
+
+static inline GradParams make_grad_params(float lambda_max, float B, float B2, float nu) {
+    return GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max), B, B2,
+                      (float)(1.0 / (double)nu)};
+}
+
+size_t gs_icp_tape_bytes(int max_ns, int numiters, int grad_lm) {
+    return tape_layout(grad_lm != 0, max_ns > 0 ? max_ns : 1, numiters, nullptr, nullptr);
+}
+
+int gs_icp_point_to_plane_taped(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
+                                const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp,
+                                float dist_thresh, int grad_lm, float lambda_max, float B, float B2, float nu,
+                                const gs_icp_hints *hints, float *out_T, uint64_t *best_last, void *tape, size_t tape_bytes,
+                                void *ws, size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(tape, "gs_icp_point_to_plane_taped: NULL tape");
+    return icp_run(grad_lm != 0, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, damp, dist_thresh,
+                   grad_lm ? make_grad_params(lambda_max, B, B2, nu) : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f}, hints, out_T,
+                   best_last, nullptr, ws, ws_bytes, (hipStream_t)stream, "gs_icp_point_to_plane_taped", tape, tape_bytes);
+}
+
+size_t gs_icp_backward_ws_bytes(int max_ns) { return bwd_ws_layout(max_ns > 0 ? max_ns : 1, nullptr, nullptr); }
+
+int gs_icp_point_to_plane_backward(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
+                                   int max_nt, const float *init_T, int numiters, float dist_thresh, int grad_lm,
+                                   float lambda_max, float B, float B2, float nu, const void *tape, size_t tape_bytes,
+                                   const float *grad_T, float *grad_src, float *grad_tgt, float *grad_normals,
+                                   float *grad_init_T, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    if (numiters == 0) {  // T = init_T, nothing else depends on the inputs
+        GS_REQUIRE(grad_T && grad_src && grad_init_T && max_ns > 0 && max_nt > 0, "gs_icp_point_to_plane_backward: bad arguments");
+        hipStream_t st = (hipStream_t)stream;
+        GS_HIP(hipMemsetAsync(grad_src, 0, (size_t)max_ns * 12, st), "gs_icp_point_to_plane_backward");
+        if (grad_tgt) GS_HIP(hipMemsetAsync(grad_tgt, 0, (size_t)max_nt * 12, st), "gs_icp_point_to_plane_backward");
+        if (grad_normals) GS_HIP(hipMemsetAsync(grad_normals, 0, (size_t)max_nt * 12, st), "gs_icp_point_to_plane_backward");
+        GS_HIP(hipMemcpyAsync(grad_init_T, grad_T, 64, hipMemcpyDeviceToDevice, st), "gs_icp_point_to_plane_backward");
+        return GS_OK;
+    }
+    return icp_backward_run(grad_lm != 0, src, d_ns, max_ns, tgt, tgt_normals, max_nt, init_T, numiters, dist_thresh,
+                            grad_lm ? make_grad_params(lambda_max, B, B2, nu) : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f}, tape,
+                            tape_bytes, grad_T, grad_src, grad_tgt, grad_normals, grad_init_T, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -5,10 +5,13 @@ runs in hand-written HIP kernels (gradslam_amd/csrc/icp.hip):
 
 * nearest-neighbour association: exact brute-force K=1 search (replaces chamferdist.knn_points);
 * `gauss_newton_solve` rows / the fused linearise + 6x6 reduce;
-* `point_to_plane_ICP` / `point_to_plane_gradICP`: when no input requires grad the WHOLE loop --
-  association, linearisation, 6x6 solve, SE(3) exponential, LM accept/reject -- runs on the device
-  with no host round trip (`gs_icp_point_to_plane[_grad]`); when gradients are needed the loop is
-  unrolled in Python over differentiable kernels so autograd sees the same graph as the reference.
+* `point_to_plane_ICP` / `point_to_plane_gradICP`: the WHOLE loop -- association, linearisation,
+  6x6 solve, SE(3) exponential, LM accept/reject -- runs on the device with no host round trip
+  (`gs_icp_point_to_plane[_grad]`).  When gradients are needed the same loop runs taped
+  (`gs_icp_point_to_plane_taped`) as ONE autograd node whose backward walks the tape on the device
+  (`gs_icp_point_to_plane_backward`).  `FUSED_AUTOGRAD = False` selects the older formulation --
+  the loop unrolled in Python over differentiable kernels, one autograd node per op like the
+  reference's graph -- which the tests use as an independent check of the fused reverse pass.
 """
 from typing import Optional, Union
 
@@ -19,6 +22,8 @@ from ..geometry.geometryutils import transform_pointcloud
 from ..geometry.se3utils import se3_exp
 from ..structures.pointclouds import Pointclouds
 from ..structures.rgbdimages import RGBDImages
+
+FUSED_AUTOGRAD = True
 
 __all__ = ["solve_linear_system", "gauss_newton_solve", "point_to_plane_ICP", "point_to_plane_gradICP",
            "downsample_pointclouds", "downsample_rgbdimages"]
@@ -142,7 +147,11 @@ def point_to_plane_ICP(src_pc: torch.Tensor, tgt_pc: torch.Tensor, tgt_normals: 
                                          dist_thresh, want_best=True)
         return T, (_unpack_last(best, dist_thresh) if numiters > 0 else None)
 
-    # differentiable path: same kernels, loop unrolled for autograd; the LM branch costs one host
+    if FUSED_AUTOGRAD:
+        T, best = ops.icp_loop_autograd(src_pc[0], tgt_pc[0], tgt_normals[0], initial_transform, numiters, damp, dist_thresh)
+        return T, (_unpack_last(best, dist_thresh) if numiters > 0 else None)
+
+    # unrolled differentiable path: same kernels, one autograd node per op; the LM branch costs one host
     # sync per iteration exactly like the reference (:356).
     src = transform_pointcloud(src_pc[0].contiguous(), initial_transform)
     tgt, nrm = tgt_pc[0].contiguous(), tgt_normals[0].contiguous()
@@ -181,6 +190,11 @@ def point_to_plane_gradICP(src_pc: torch.Tensor, tgt_pc: torch.Tensor, tgt_norma
     if not _wants_grad(src_pc, tgt_pc, tgt_normals, initial_transform):
         T, best, _ = ops.icp_device_loop(src_pc[0], tgt_pc[0], tgt_normals[0], initial_transform, numiters, damp,
                                          dist_thresh, grad_params=(lambda_max, B, B2, nu), want_best=True)
+        return T, (_unpack_last(best, dist_thresh) if numiters > 0 else None)
+
+    if FUSED_AUTOGRAD:
+        T, best = ops.icp_loop_autograd(src_pc[0], tgt_pc[0], tgt_normals[0], initial_transform, numiters, damp, dist_thresh,
+                                        grad_params=(lambda_max, B, B2, nu))
         return T, (_unpack_last(best, dist_thresh) if numiters > 0 else None)
 
     src = transform_pointcloud(src_pc[0].contiguous(), initial_transform)

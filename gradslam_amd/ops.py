@@ -374,6 +374,57 @@ def icp_device_loop(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_par
     return T, best, trace
 
 
+class _IcpLoopFn(torch.autograd.Function):
+    """Differentiable point_to_plane_ICP / gradICP as ONE node: the taped device loop forward, the
+    device-side reverse pass over the tape backward (no host sync in either direction)."""
+
+    @staticmethod
+    def forward(ctx, src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_params):
+        src, tgt, nrm, init_T = _f32c(src.detach()), _f32c(tgt.detach()), _f32c(nrm.detach()), _f32c(init_T.detach())
+        dev = src.device
+        ns, nt = src.shape[0], tgt.shape[0]
+        if ns == 0 or nt == 0:
+            raise ValueError("ICP needs non-empty source and target clouds (got {} and {} points)".format(ns, nt))
+        grad_lm = 1 if grad_params is not None else 0
+        lmax, Bp, B2, nu = grad_params if grad_params is not None else (2.0, 1.0, 1.0, 200.0)
+        T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+        best = torch.empty(ns, dtype=torch.int64, device=dev)
+        tape = torch.empty(ws_bytes("gs_icp_tape_bytes", ns, int(numiters), grad_lm), dtype=torch.uint8, device=dev)
+        ws = workspace(ws_bytes("gs_icp_ws_bytes", ns, nt), dev, "icp")
+        d_ns, d_nt = dev_int(ns, dev), dev_int(nt, dev)
+        call("gs_icp_point_to_plane_taped", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),
+             int(numiters), float(damp), _thresh(dist_thresh), grad_lm, float(lmax), float(Bp), float(B2), float(nu), None,
+             ptr(T), ptr(best), ptr(tape), tape.numel(), ptr(ws), ws.numel(), stream())
+        ctx.save_for_backward(src, tgt, nrm, init_T, tape, d_ns)
+        ctx.cfg = (int(numiters), _thresh(dist_thresh), grad_lm, float(lmax), float(Bp), float(B2), float(nu))
+        ctx.mark_non_differentiable(best)
+        return T, best
+
+    @staticmethod
+    def backward(ctx, gT, _gbest):
+        src, tgt, nrm, init_T, tape, d_ns = ctx.saved_tensors
+        numiters, thresh, grad_lm, lmax, Bp, B2, nu = ctx.cfg
+        dev = src.device
+        ns, nt = src.shape[0], tgt.shape[0]
+        gT = _f32c(gT)
+        need_tgt, need_nrm = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g_src = torch.empty_like(src)
+        g_tgt = torch.empty_like(tgt) if need_tgt else None
+        g_nrm = torch.empty_like(nrm) if need_nrm else None
+        g_init = torch.empty((4, 4), dtype=torch.float32, device=dev)
+        ws = workspace(ws_bytes("gs_icp_backward_ws_bytes", ns), dev, "icp_bwd")
+        call("gs_icp_point_to_plane_backward", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), nt, ptr(init_T), numiters, thresh,
+             grad_lm, lmax, Bp, B2, nu, ptr(tape), tape.numel(), ptr(gT), ptr(g_src), ptr(g_tgt), ptr(g_nrm), ptr(g_init),
+             ptr(ws), ws.numel(), stream())
+        return g_src, g_tgt, g_nrm, g_init, None, None, None, None
+
+
+def icp_loop_autograd(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_params=None):
+    """(T (4,4) with grad_fn, packed NN of the last iteration's first solve)."""
+    require_hip(src, tgt, nrm, init_T, op="icp")
+    return _IcpLoopFn.apply(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_params)
+
+
 def slam_localize_raw(depth, K, prev_poses, map_points, map_normals, map_counts_i32, ds, numiters, damp, dist_thresh,
                       grad_params=None):
     """One fused, sync-free ICPSLAM._localize (reference slam/icpslam.py:238-247).

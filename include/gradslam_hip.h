@@ -221,6 +221,33 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
                                const gs_icp_hints *hints, float *out_T, uint64_t *best_last,
                                float *trace, void *ws, size_t ws_bytes, gs_stream_t stream);
 
+/* ---------------------------------------------------------------- X with autograd: taped loops + reverse pass
+ * The differentiable form of point_to_plane_ICP / point_to_plane_gradICP (odometry/icputils.py:310-367,
+ * :479-545; gradients as torch autograd derives them for the reference: through the rigid transforms,
+ * the linearisation, the damped solve, se3_exp and -- gradLM only -- the damping / step gates; the
+ * association indices and the LM accept/reject decisions are constants).
+ * Forward: same loop and results as gs_icp_point_to_plane[_grad], but every association launch keeps its
+ * cloud and neighbour array, and every step its state, in the caller's `tape` (gs_icp_tape_bytes).
+ * Backward: given grad_T (device 4x4, adjoint of out_T) walks the tape in reverse on the device with no
+ * host synchronisation and writes grad_src (max_ns,3), grad_tgt / grad_normals (max_nt,3; optional, NULL
+ * to skip) and grad_init_T (4x4).  grad_lm selects the gradLM variant (0: LM, parameters ignored). */
+size_t gs_icp_tape_bytes(int max_ns, int numiters, int grad_lm);
+int gs_icp_point_to_plane_taped(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                                const float *tgt_normals, const int32_t *d_nt, int max_nt,
+                                const float *init_T, int numiters, float damp, float dist_thresh,
+                                int grad_lm, float lambda_max, float B, float B2, float nu,
+                                const gs_icp_hints *hints, float *out_T, uint64_t *best_last,
+                                void *tape, size_t tape_bytes, void *ws, size_t ws_bytes,
+                                gs_stream_t stream);
+size_t gs_icp_backward_ws_bytes(int max_ns);
+int gs_icp_point_to_plane_backward(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
+                                   const float *tgt_normals, int max_nt, const float *init_T,
+                                   int numiters, float dist_thresh, int grad_lm, float lambda_max,
+                                   float B, float B2, float nu, const void *tape, size_t tape_bytes,
+                                   const float *grad_T, float *grad_src, float *grad_tgt,
+                                   float *grad_normals, float *grad_init_T, void *ws, size_t ws_bytes,
+                                   gs_stream_t stream);
+
 /* ---------------------------------------------------------------- whole localisation step
  * ICPSLAM._localize for odom in {icp, gradicp} (slam/icpslam.py:238-247) as ONE call with no host
  * synchronisation: live-frame maps posed with the previous pose (rgbdimages.py:643-762), ds-grid

@@ -291,6 +291,70 @@ def test_icp_grad_path_matches_device_loop(gs, golden):
     assert torch.isfinite(s2.grad).all() and s2.grad.abs().sum() > 0
 
 
+ICP_GRAD_CASES = [("icp_n1", False, dict(numiters=1, damp=1e-8, dist_thresh=None)),
+                  ("icp_n4", False, dict(numiters=4, damp=1e-8, dist_thresh=None)),
+                  ("icp_n4_th", False, dict(numiters=4, damp=1e-8, dist_thresh=2e-4)),
+                  ("icp_n3_damp", False, dict(numiters=3, damp=1e-2, dist_thresh=None)),
+                  ("gradicp_n1", True, dict(numiters=1, damp=1e-8, dist_thresh=None)),
+                  ("gradicp_n3", True, dict(numiters=3, damp=1e-8, dist_thresh=None)),
+                  ("gradicp_n3_th", True, dict(numiters=3, damp=1e-8, dist_thresh=2e-4)),
+                  ("gradicp_n3_damp", True, dict(numiters=3, damp=1e-2, dist_thresh=None, lambda_max=3.0, B=0.7, B2=1.3, nu=50.0))]
+
+
+def _icp_grads(gs, g, grad_lm, kw, fused):
+    ut = gs.odometry.icputils
+    s, tg, n, T0 = (d(g[k]).clone().requires_grad_(True) for k in ("src", "tgt", "tgt_n", "T0"))
+    old, ut.FUSED_AUTOGRAD = ut.FUSED_AUTOGRAD, fused
+    try:
+        fn = ut.point_to_plane_gradICP if grad_lm else ut.point_to_plane_ICP
+        T, _ = fn(s[None], tg[None], n[None], T0, **kw)
+        (T * d(g["W"])).sum().backward()
+    finally:
+        ut.FUSED_AUTOGRAD = old
+    return T.detach().cpu(), [x.grad.cpu() for x in (s, tg, n, T0)]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_reverse_pass", "unrolled_autograd"])
+def test_icp_input_gradients_vs_reference(gs, golden, fused):
+    """Input gradients of point_to_plane_ICP / gradICP against the reference's own autograd
+    (tests/golden/ref_icp_grads.npz, tools/gen_golden_icp_grads.py).  Tolerance: 1e-4 of the largest
+    reference entry per tensor (north_star's bound; measured worst case 2.2e-5)."""
+    g = golden("ref_icp_grads")
+    worst = 0.0
+    for name, grad_lm, kw in ICP_GRAD_CASES:
+        T, grads = _icp_grads(gs, g, grad_lm, kw, fused)
+        assert rel_err(T, t(g[name + "_T"])) < 1e-4, name
+        for key, mine in zip(("g_src", "g_tgt", "g_nrm", "g_T0"), grads):
+            ref = t(g[name + "_" + key])
+            e = rel_err(mine, ref)
+            worst = max(worst, e)
+            print(name, key, "rel err %.2e" % e)
+            assert torch.isfinite(mine).all() and e < 1e-4, (name, key, e)
+    print("worst", worst)
+
+
+def test_fused_reverse_pass_matches_unrolled_autograd_at_size(gs):
+    """19 200-point clouds (160x120 ds=1), 10 iterations, both variants: the one-node reverse pass against
+    the per-op autograd graph over the same kernels (same associations, same accept decisions)."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(1, 2, 120, 160, seed=3)
+    r = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P[:, :1].repeat(1, 2, 1, 1).to(DEV))
+    tgt_pc = gs.structures.utils.pointclouds_from_rgbdimages(r[:, 0])
+    src_pc = gs.structures.utils.pointclouds_from_rgbdimages(r[:, 1])
+    torch.manual_seed(0)
+    g = dict(src=src_pc.points_list[0], tgt=tgt_pc.points_list[0], tgt_n=tgt_pc.normals_list[0], T0=torch.eye(4),
+             W=torch.randn(4, 4))
+    for grad_lm, kw in ((False, dict(numiters=10, damp=1e-8, dist_thresh=None)), (True, dict(numiters=10, damp=1e-8, dist_thresh=None)),
+                        (False, dict(numiters=6, damp=1e-8, dist_thresh=1e-3)), (True, dict(numiters=6, damp=1e-8, dist_thresh=1e-3))):
+        Ta, ga = _icp_grads(gs, g, grad_lm, kw, True)
+        Tb, gb = _icp_grads(gs, g, grad_lm, kw, False)
+        assert rel_err(Ta, Tb) < 1e-5
+        for key, a, b in zip(("g_src", "g_tgt", "g_nrm", "g_T0"), ga, gb):
+            print("gradLM" if grad_lm else "LM", kw["numiters"], key, "rel err %.2e" % rel_err(a, b), "|ref| %.3e" % float(b.abs().max()))
+            assert rel_err(a, b) < 3e-4, (grad_lm, key)  # measured 6e-5
+
+
 # ------------------------------------------------------------------ P / S / D
 def test_active_points_and_downsample_vs_oracle(gs, golden):
     from oracle import fusion, icp

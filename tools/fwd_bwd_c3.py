@@ -11,7 +11,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 odom = sys.argv[2] if len(sys.argv) > 2 else "gradicp"
 dev = "cuda:0"
 c, d, K, P = make_sequence(1, n, 480, 640, seed=7)
-for rep in range(2):
+for rep in range(3):
+    pcs = poses = loss = None
     cc, dd, kk, pp = (x.to(dev).clone().requires_grad_(True) for x in (c, d, K, P))
     slam = gs.slam.PointFusion(odom=odom, dsratio=4, numiters=10, device=dev)
     torch.cuda.synchronize(); t0 = time.perf_counter()
