@@ -34,7 +34,7 @@ SIGNATURES = {
     "gs_downsample_frame": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_build_icp_target_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "gs_build_icp_target": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                  c_sz, c_p]),
+                                  c_p, c_sz, c_p]),
     "gs_bucket_by_pixel_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "gs_bucket_by_pixel": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_project_active_ws_bytes": (c_sz, [c_i, c_i]),
@@ -60,8 +60,14 @@ SIGNATURES = {
     "gs_icp_point_to_plane_taped": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f,
                                           c_p, c_p, c_p, c_p, c_sz, c_p, c_sz, c_p]),
     "gs_icp_backward_ws_bytes": (c_sz, [c_i]),
-    "gs_icp_point_to_plane_backward": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_p, c_sz,
+    "gs_icp_point_to_plane_backward": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_p, c_sz,
                                              c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_slam_localize_tape_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "gs_slam_localize_taped": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
+                                     c_f, c_f, c_p, c_p, c_sz, c_p, c_sz, c_p]),
+    "gs_slam_localize_backward_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "gs_slam_localize_backward": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_sz,
+                                        c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compose_poses": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "gs_set_graph_mode": (None, [c_i]),
     "gs_slam_localize_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),

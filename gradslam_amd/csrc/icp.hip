@@ -1480,12 +1480,20 @@ static inline size_t bwd_ws_layout(int max_ns, void *ws, BwdWs *out) {
     return oP + align_up((size_t)BWD_MAXB * 12 * 4, 256);
 }
 
+__global__ void zero_rows_k(float *__restrict__ a, float *__restrict__ b, const int32_t *__restrict__ d_n, int cap) {
+    const int n = 3 * min(*d_n, cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (a) a[i] = 0.0f;
+        if (b) b[i] = 0.0f;
+    }
+}
+
 static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
-                            int max_nt, const float *init_T, int numiters, float thresh, GradParams gp, const void *tape,
+                            const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float thresh, GradParams gp, const void *tape,
                             size_t tape_bytes, const float *grad_T, float *g_src, float *g_tgt, float *g_nrm, float *g_init_T,
                             void *ws, size_t ws_bytes, hipStream_t st) {
     const char *name = "gs_icp_backward";
-    GS_REQUIRE(src && d_ns && tgt && nrm && init_T && tape && grad_T && g_src && g_init_T, "%s: NULL argument", name);
+    GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && init_T && tape && grad_T && g_src && g_init_T, "%s: NULL argument", name);
     GS_REQUIRE(max_ns > 0 && max_nt > 0 && numiters >= 0, "%s: bad sizes", name);
     if (!ws || ws_bytes < bwd_ws_layout(max_ns, nullptr, nullptr)) {
         set_error("%s: workspace too small", name);
@@ -1498,8 +1506,8 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
     bwd_ws_layout(max_ns, ws, &w);
     const int nb = min(cdiv(max_ns, BWD_T), BWD_MAXB);
     GS_HIP(hipMemsetAsync(w.gP, 0, (size_t)max_ns * 12, st), name);
-    if (g_tgt) GS_HIP(hipMemsetAsync(g_tgt, 0, (size_t)max_nt * 12, st), name);
-    if (g_nrm) GS_HIP(hipMemsetAsync(g_nrm, 0, (size_t)max_nt * 12, st), name);
+    if (g_tgt || g_nrm)  // only the rows that exist (max_nt may be a generous capacity)
+        hipLaunchKernelGGL(zero_rows_k, dim3(min(cdiv(3 * max_nt, 256), 1024)), dim3(256), 0, st, g_tgt, g_nrm, d_nt, max_nt);
     hipLaunchKernelGGL(bwd_init_k, dim3(1), dim3(64), 0, st, w.S, grad_T);
     for (int k = numiters - 1; k >= 0; --k) {
         if (!grad) {
@@ -1708,20 +1716,20 @@ int gs_icp_point_to_plane_taped(const float *src, const int32_t *d_ns, int max_n
 size_t gs_icp_backward_ws_bytes(int max_ns) { return bwd_ws_layout(max_ns > 0 ? max_ns : 1, nullptr, nullptr); }
 
 int gs_icp_point_to_plane_backward(const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *tgt_normals,
-                                   int max_nt, const float *init_T, int numiters, float dist_thresh, int grad_lm,
+                                   const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float dist_thresh, int grad_lm,
                                    float lambda_max, float B, float B2, float nu, const void *tape, size_t tape_bytes,
                                    const float *grad_T, float *grad_src, float *grad_tgt, float *grad_normals,
                                    float *grad_init_T, void *ws, size_t ws_bytes, gs_stream_t stream) {
     if (numiters == 0) {  // T = init_T, nothing else depends on the inputs
-        GS_REQUIRE(grad_T && grad_src && grad_init_T && max_ns > 0 && max_nt > 0, "gs_icp_point_to_plane_backward: bad arguments");
+        GS_REQUIRE(grad_T && grad_src && grad_init_T && d_nt && max_ns > 0 && max_nt > 0, "gs_icp_point_to_plane_backward: bad arguments");
         hipStream_t st = (hipStream_t)stream;
         GS_HIP(hipMemsetAsync(grad_src, 0, (size_t)max_ns * 12, st), "gs_icp_point_to_plane_backward");
-        if (grad_tgt) GS_HIP(hipMemsetAsync(grad_tgt, 0, (size_t)max_nt * 12, st), "gs_icp_point_to_plane_backward");
-        if (grad_normals) GS_HIP(hipMemsetAsync(grad_normals, 0, (size_t)max_nt * 12, st), "gs_icp_point_to_plane_backward");
+        if (grad_tgt || grad_normals)
+            hipLaunchKernelGGL(zero_rows_k, dim3(min(cdiv(3 * max_nt, 256), 1024)), dim3(256), 0, st, grad_tgt, grad_normals, d_nt, max_nt);
         GS_HIP(hipMemcpyAsync(grad_init_T, grad_T, 64, hipMemcpyDeviceToDevice, st), "gs_icp_point_to_plane_backward");
         return GS_OK;
     }
-    return icp_backward_run(grad_lm != 0, src, d_ns, max_ns, tgt, tgt_normals, max_nt, init_T, numiters, dist_thresh,
+    return icp_backward_run(grad_lm != 0, src, d_ns, max_ns, tgt, tgt_normals, d_nt, max_nt, init_T, numiters, dist_thresh,
                             grad_lm ? make_grad_params(lambda_max, B, B2, nu) : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f}, tape,
                             tape_bytes, grad_T, grad_src, grad_tgt, grad_normals, grad_init_T, ws, ws_bytes, (hipStream_t)stream);
 }

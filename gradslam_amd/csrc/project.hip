@@ -198,7 +198,7 @@ __global__ void tgt_gather_count_k(const int64_t *__restrict__ rows, const int32
                                    const int32_t *__restrict__ starts, const float *__restrict__ map_points,
                                    const float *__restrict__ map_normals, int B, int Nmax, int cap,
                                    float *__restrict__ tgt, float *__restrict__ tnrm, int32_t *__restrict__ counts, int Wd,
-                                   int npix, int ds, int *__restrict__ cnt) {
+                                   int npix, int ds, int *__restrict__ cnt, int32_t *__restrict__ tgt_index) {
     const int n = *d_n;
     if (blockIdx.x == 0 && threadIdx.x < B) counts[threadIdx.x] = starts[threadIdx.x + 1] - starts[threadIdx.x];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -211,6 +211,7 @@ __global__ void tgt_gather_count_k(const int64_t *__restrict__ rows, const int32
         const int64_t src = (int64_t)b * Nmax + r.y, dst = (int64_t)b * cap + k;
         st3(tgt, dst, ld3(map_points, src));
         st3(tnrm, dst, ld3(map_normals, src));
+        if (tgt_index) tgt_index[dst] = (int32_t)r.y;
     }
 }
 
@@ -306,8 +307,8 @@ size_t gs_build_icp_target_ws_bytes(int B, int H, int W, int ds) { return gs_buc
 
 int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H, int W, int ds,
                         const float *map_points, const float *map_normals, int Nmax, int cap, float *tgt, float *tgt_normals,
-                        int32_t *counts, float *scan_points, int32_t *scan_orig, int32_t *pix_start, void *ws,
-                        size_t ws_bytes, gs_stream_t stream) {
+                        int32_t *counts, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index,
+                        void *ws, size_t ws_bytes, gs_stream_t stream) {
     GS_REQUIRE(rows && d_n_rows && map_points && map_normals && tgt && tgt_normals && counts && scan_points && scan_orig && pix_start,
                "gs_build_icp_target: NULL argument");
     GS_REQUIRE(B > 0 && B <= 256 && H > 0 && W > 0 && ds > 0 && Nmax > 0 && cap > 0 && max_rows >= 0, "gs_build_icp_target: bad shape");
@@ -326,7 +327,7 @@ int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t ma
     hipLaunchKernelGGL(table_starts_k, dim3(cdiv(B + 1, 64)), dim3(64), 0, st, rows, d_n_rows, B, starts);
     const int nb = max_rows > 0 ? min(cdiv(max_rows, 256), 1024) : 1;
     hipLaunchKernelGGL(tgt_gather_count_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, map_points, map_normals, B, Nmax,
-                       cap, tgt, tgt_normals, counts, Wd, npix, ds, cnt);
+                       cap, tgt, tgt_normals, counts, Wd, npix, ds, cnt, tgt_index);
     hipLaunchKernelGGL(pix_scan_k, dim3(B), dim3(1024), 0, st, cnt, npix, pix_start);
     hipLaunchKernelGGL(pix_scatter_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, pix_start, fill, map_points,
                        Nmax, cap, scan_points, scan_orig);

@@ -118,6 +118,84 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     return off;
 }
 
+// ------------------------------------------------------------------ differentiable localisation
+// Tape of one gs_slam_localize_taped call: what the reverse pass cannot cheaply recompute.
+struct LocTape {
+    float *src;         // (B, capS, 3) ds-grid source cloud
+    int32_t *src_pix;   // (B, capS)   ds-grid pixel of every source point
+    int32_t *ns, *nt;   // (B)
+    int32_t *tgt_index; // (B, capT)   map index of every target slot
+    float *T;           // (B, 16)     ICP result (before composition with the previous pose)
+    char *icp;          // B x icp_tape bytes
+    size_t icp_bytes;
+};
+static size_t loc_tape_layout(int B, int H, int W, int ds, int Nmax, int numiters, int grad_lm, void *tape, LocTape *out) {
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t o_src = take((size_t)B * capS * 12), o_pix = take((size_t)B * capS * 4), o_ns = take((size_t)B * 4);
+    const size_t o_nt = take((size_t)B * 4), o_idx = take((size_t)B * capT * 4), o_T = take((size_t)B * 64);
+    const size_t icp_b = align_up(gs_icp_tape_bytes(capS, numiters, grad_lm), 256);
+    const size_t o_icp = take((size_t)B * icp_b);
+    if (tape && out) {
+        char *p = (char *)tape;
+        out->src = (float *)(p + o_src); out->src_pix = (int32_t *)(p + o_pix);
+        out->ns = (int32_t *)(p + o_ns); out->nt = (int32_t *)(p + o_nt);
+        out->tgt_index = (int32_t *)(p + o_idx); out->T = (float *)(p + o_T);
+        out->icp = p + o_icp; out->icp_bytes = icp_b;
+    }
+    return off;
+}
+
+// adjoint of compose_k: out = T . P
+__global__ void compose_bwd_k(const float *__restrict__ T, const float *__restrict__ P, const float *__restrict__ gO, int B,
+                              float *__restrict__ gT, float *__restrict__ gP) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *a = T + 16 * b, *p = P + 16 * b, *g = gO + 16 * b;
+    float *ga = gT + 16 * b, *gp = gP + 16 * b;
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 3; ++k) ga[4 * i + k] = ((g[4 * i] * p[4 * k] + g[4 * i + 1] * p[4 * k + 1]) + g[4 * i + 2] * p[4 * k + 2]) + g[4 * i + 3] * p[4 * k + 3];
+        ga[4 * i + 3] = g[4 * i + 3];
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 4; ++j) gp[4 * k + j] = (a[k] * g[j] + a[4 + k] * g[4 + j]) + a[8 + k] * g[8 + j];
+    for (int j = 0; j < 4; ++j) { ga[12 + j] = 0.0f; gp[12 + j] = 0.0f; }
+}
+
+// target / normals of every slot again from the map (what gs_build_icp_target gathered in the forward pass)
+__global__ void regather_k(const int32_t *__restrict__ tgt_index, const int32_t *__restrict__ nt, int capT,
+                           const float *__restrict__ map_points, const float *__restrict__ map_normals, int Nmax,
+                           float *__restrict__ tgt, float *__restrict__ tnrm) {
+    const int b = blockIdx.y, n = min(nt[b], capT);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int64_t srcI = (int64_t)b * Nmax + tgt_index[(int64_t)b * capT + k], dst = (int64_t)b * capT + k;
+        st3(tgt, dst, ld3(map_points, srcI));
+        st3(tnrm, dst, ld3(map_normals, srcI));
+    }
+}
+
+// adjoints back to where the clouds came from: source slot i -> its ds-grid pixel of the (zeroed) global vertex
+// map adjoint; target slot k -> its map point (every map point is at most one slot: plain stores)
+__global__ void scatter_grads_k(const float *__restrict__ g_src, const int32_t *__restrict__ src_pix, const int32_t *__restrict__ ns,
+                                int capS, int Wd, int ds, int H, int W, float *__restrict__ g_gvertex /* this b */,
+                                const float *__restrict__ g_tgt, const float *__restrict__ g_nrm,
+                                const int32_t *__restrict__ tgt_index, const int32_t *__restrict__ nt, int capT,
+                                float *__restrict__ g_map_points, float *__restrict__ g_map_normals /* this b */) {
+    const int n_s = min(*ns, capS), n_t = min(*nt, capT);
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s; i += stride) {
+        const int pix = src_pix[i];
+        const int64_t at = (int64_t)(pix / Wd) * ds * W + (int64_t)(pix % Wd) * ds;
+        st3(g_gvertex, at, ld3(g_src, i));
+    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_t; k += stride) {
+        const int64_t at = tgt_index[k];
+        if (g_map_points) st3(g_map_points, at, ld3(g_tgt, k));
+        if (g_map_normals) st3(g_map_normals, at, ld3(g_nrm, k));
+    }
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -165,7 +243,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     // reference-order target (points, normals, counts) + the same points in pixel order and one seed
     // per ds-grid pixel (search hints only)
     if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
-                                  w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, w.sub, w.sub_bytes, stream))) return rc;
+                                  w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.sub, w.sub_bytes, stream))) return rc;
     hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
     GS_LAUNCH_CHECK("gs_slam_localize/eye");
     auto enqueue_loops = [&](gs_stream_t s) -> int {
@@ -239,6 +317,114 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     }
     if (!launched && (rc = enqueue_loops(stream))) return rc;
     return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);
+}
+
+size_t gs_slam_localize_tape_bytes(int B, int H, int W, int ds, int Nmax, int numiters, int use_grad_lm) {
+    if (B <= 0 || H <= 0 || W <= 0 || ds <= 0 || Nmax <= 0 || numiters < 0) return 0;
+    return loc_tape_layout(B, H, W, ds, Nmax, numiters, use_grad_lm, nullptr, nullptr);
+}
+
+int gs_slam_localize_taped(const float *depth, const float *gvertex, const float *intrinsics, const float *prev_poses, int B, int H,
+                           int W, int ds, const float *map_points, const float *map_normals, const int32_t *map_counts, int Nmax,
+                           int use_grad_lm, int numiters, float damp, float dist_thresh, float lambda_max, float Bp, float B2,
+                           float nu, float *out_poses, void *tape, size_t tape_bytes, void *ws, size_t ws_bytes,
+                           gs_stream_t stream) {
+    GS_REQUIRE(depth && gvertex && intrinsics && prev_poses && map_points && map_normals && map_counts && out_poses && tape,
+               "gs_slam_localize_taped: NULL argument");
+    GS_REQUIRE(B > 0 && H >= 2 && W >= 2 && ds > 0 && Nmax > 0 && numiters >= 0, "gs_slam_localize_taped: bad shape");
+    if (!ws || ws_bytes < gs_slam_localize_ws_bytes(B, H, W, ds, Nmax)) {
+        set_error("gs_slam_localize_taped: workspace too small (%zu < %zu)", ws_bytes, gs_slam_localize_ws_bytes(B, H, W, ds, Nmax));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    GS_REQUIRE(tape_bytes >= gs_slam_localize_tape_bytes(B, H, W, ds, Nmax, numiters, use_grad_lm),
+               "gs_slam_localize_taped: tape too small");
+    hipStream_t st = (hipStream_t)stream;
+    LocWs w;
+    loc_layout(B, H, W, ds, Nmax, ws, &w);
+    LocTape tp;
+    loc_tape_layout(B, H, W, ds, Nmax, numiters, use_grad_lm, tape, &tp);
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
+    int rc;
+    if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, tp.src, nullptr, nullptr, tp.src_pix, tp.ns,
+                                  w.sub, w.sub_bytes, stream))) return rc;
+    if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
+                                w.sub_bytes, stream))) return rc;
+    if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
+                                  w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.sub, w.sub_bytes, stream))) return rc;
+    hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
+    GS_LAUNCH_CHECK("gs_slam_localize_taped/eye");
+    for (int b = 0; b < B; ++b) {
+        const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, tp.src_pix + (size_t)b * capS,
+                                 w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
+        if ((rc = gs_icp_point_to_plane_taped(tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
+                                              w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                                              dist_thresh, use_grad_lm, lambda_max, Bp, B2, nu, &hints, tp.T + 16 * b, nullptr,
+                                              tp.icp + (size_t)b * tp.icp_bytes, tp.icp_bytes, w.sub, w.sub_bytes, stream)))
+            return rc;
+    }
+    return gs_compose_poses(tp.T, prev_poses, B, out_poses, stream);
+}
+
+size_t gs_slam_localize_backward_ws_bytes(int B, int H, int W, int ds, int Nmax) {
+    if (B <= 0 || H <= 0 || W <= 0 || ds <= 0 || Nmax <= 0) return 0;
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
+    // tgt, tnrm, g_tgt, g_nrm (one batch element at a time) + g_src + g_T, g_init, eye + the ICP reverse pass's own
+    return 4 * align_up((size_t)capT * 12, 256) + align_up((size_t)capS * 12, 256) + 3 * align_up((size_t)B * 64, 256) +
+           align_up(gs_icp_backward_ws_bytes(capS), 256);
+}
+
+int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int ds, const float *map_points,
+                              const float *map_normals, int Nmax, int use_grad_lm, int numiters, float dist_thresh,
+                              float lambda_max, float Bp, float B2, float nu, const void *tape, size_t tape_bytes,
+                              const float *grad_out_poses, float *grad_gvertex, float *grad_map_points, float *grad_map_normals,
+                              float *grad_prev_poses, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    const char *name = "gs_slam_localize_backward";
+    GS_REQUIRE(prev_poses && map_points && map_normals && tape && grad_out_poses && grad_gvertex && grad_prev_poses,
+               "%s: NULL argument", name);
+    GS_REQUIRE(B > 0 && H >= 2 && W >= 2 && ds > 0 && Nmax > 0 && numiters >= 0, "%s: bad shape", name);
+    if (!ws || ws_bytes < gs_slam_localize_backward_ws_bytes(B, H, W, ds, Nmax)) {
+        set_error("%s: workspace too small", name);
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    GS_REQUIRE(tape_bytes >= gs_slam_localize_tape_bytes(B, H, W, ds, Nmax, numiters, use_grad_lm), "%s: tape too small", name);
+    hipStream_t st = (hipStream_t)stream;
+    LocTape tp;
+    loc_tape_layout(B, H, W, ds, Nmax, numiters, use_grad_lm, (void *)tape, &tp);
+    const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
+    char *p = (char *)ws;
+    auto take = [&](size_t bytes) { char *o = p; p += align_up(bytes, 256); return o; };
+    float *tgt = (float *)take((size_t)capT * 12), *tnrm = (float *)take((size_t)capT * 12);
+    float *g_tgt = (float *)take((size_t)capT * 12), *g_nrm = (float *)take((size_t)capT * 12);
+    float *g_src = (float *)take((size_t)capS * 12);
+    float *g_T = (float *)take((size_t)B * 64), *g_init = (float *)take((size_t)B * 64), *eye = (float *)take((size_t)B * 64);
+    void *sub = p;
+    const size_t sub_bytes = gs_icp_backward_ws_bytes(capS);
+
+    GS_HIP(hipMemsetAsync(grad_gvertex, 0, (size_t)B * H * W * 12, st), name);
+    if (grad_map_points) GS_HIP(hipMemsetAsync(grad_map_points, 0, (size_t)B * Nmax * 12, st), name);
+    if (grad_map_normals) GS_HIP(hipMemsetAsync(grad_map_normals, 0, (size_t)B * Nmax * 12, st), name);
+    hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, eye, B);
+    hipLaunchKernelGGL(compose_bwd_k, dim3(cdiv(B, 64)), dim3(64), 0, st, tp.T, prev_poses, grad_out_poses, B, g_T, grad_prev_poses);
+    GS_LAUNCH_CHECK(name);
+    const int gb = min(cdiv(capS, 256), 512);
+    for (int b = 0; b < B; ++b) {
+        // NB the gathered arrays hold one batch element at a time: index them with b = 0
+        hipLaunchKernelGGL(regather_k, dim3(gb, 1), dim3(256), 0, st, tp.tgt_index + (size_t)b * capT, tp.nt + b, capT,
+                           map_points + (size_t)b * Nmax * 3, map_normals + (size_t)b * Nmax * 3, Nmax, tgt, tnrm);
+        GS_LAUNCH_CHECK(name);
+        int rc;
+        if ((rc = gs_icp_point_to_plane_backward(tp.src + (size_t)b * capS * 3, tp.ns + b, capS, tgt, tnrm, tp.nt + b, capT, eye + 16 * b, numiters,
+                                                 dist_thresh, use_grad_lm, lambda_max, Bp, B2, nu, tp.icp + (size_t)b * tp.icp_bytes,
+                                                 tp.icp_bytes, g_T + 16 * b, g_src, grad_map_points ? g_tgt : nullptr,
+                                                 grad_map_normals ? g_nrm : nullptr, g_init + 16 * b, sub, sub_bytes, stream)))
+            return rc;
+        hipLaunchKernelGGL(scatter_grads_k, dim3(gb), dim3(256), 0, st, g_src, tp.src_pix + (size_t)b * capS, tp.ns + b, capS,
+                           cdiv(W, ds), ds, H, W, grad_gvertex + (size_t)b * H * W * 3, g_tgt, g_nrm, tp.tgt_index + (size_t)b * capT,
+                           tp.nt + b, capT, grad_map_points ? grad_map_points + (size_t)b * Nmax * 3 : nullptr,
+                           grad_map_normals ? grad_map_normals + (size_t)b * Nmax * 3 : nullptr);
+        GS_LAUNCH_CHECK(name);
+    }
+    return GS_OK;
 }
 
 }  // extern "C"

@@ -395,14 +395,14 @@ class _IcpLoopFn(torch.autograd.Function):
         call("gs_icp_point_to_plane_taped", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T),
              int(numiters), float(damp), _thresh(dist_thresh), grad_lm, float(lmax), float(Bp), float(B2), float(nu), None,
              ptr(T), ptr(best), ptr(tape), tape.numel(), ptr(ws), ws.numel(), stream())
-        ctx.save_for_backward(src, tgt, nrm, init_T, tape, d_ns)
+        ctx.save_for_backward(src, tgt, nrm, init_T, tape, d_ns, d_nt)
         ctx.cfg = (int(numiters), _thresh(dist_thresh), grad_lm, float(lmax), float(Bp), float(B2), float(nu))
         ctx.mark_non_differentiable(best)
         return T, best
 
     @staticmethod
     def backward(ctx, gT, _gbest):
-        src, tgt, nrm, init_T, tape, d_ns = ctx.saved_tensors
+        src, tgt, nrm, init_T, tape, d_ns, d_nt = ctx.saved_tensors
         numiters, thresh, grad_lm, lmax, Bp, B2, nu = ctx.cfg
         dev = src.device
         ns, nt = src.shape[0], tgt.shape[0]
@@ -413,7 +413,7 @@ class _IcpLoopFn(torch.autograd.Function):
         g_nrm = torch.empty_like(nrm) if need_nrm else None
         g_init = torch.empty((4, 4), dtype=torch.float32, device=dev)
         ws = workspace(ws_bytes("gs_icp_backward_ws_bytes", ns), dev, "icp_bwd")
-        call("gs_icp_point_to_plane_backward", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), nt, ptr(init_T), numiters, thresh,
+        call("gs_icp_point_to_plane_backward", ptr(src), ptr(d_ns), ns, ptr(tgt), ptr(nrm), ptr(d_nt), nt, ptr(init_T), numiters, thresh,
              grad_lm, lmax, Bp, B2, nu, ptr(tape), tape.numel(), ptr(gT), ptr(g_src), ptr(g_tgt), ptr(g_nrm), ptr(g_init),
              ptr(ws), ws.numel(), stream())
         return g_src, g_tgt, g_nrm, g_init, None, None, None, None
@@ -444,6 +444,55 @@ def slam_localize_raw(depth, K, prev_poses, map_points, map_normals, map_counts_
          1 if grad_params is not None else 0, int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp),
          float(B2), float(nu), ptr(V), ptr(N), ptr(gV), None, ptr(out), ptr(ws), ws.numel(), stream())
     return out, V, N
+
+
+class _LocalizeFn(torch.autograd.Function):
+    """Differentiable ICPSLAM._localize as ONE node (gs_slam_localize_taped / _backward): gradients reach the
+    live frame's global vertex map, the map points / normals that served as ICP targets and the previous
+    pose; nothing synchronises with the host in either direction."""
+
+    @staticmethod
+    def forward(ctx, gV, depth, K, prev_poses, mp, mn, counts_i32, ds, numiters, damp, dist_thresh, grad_params):
+        gV, depth, K, prev = _f32c(gV.detach()), _f32c(depth.detach()), _f32c(K.detach()), _f32c(prev_poses.detach())
+        mp, mn = _f32c(mp.detach()), _f32c(mn.detach())
+        B, _, H, W = depth.shape[:4]
+        Nmax = mp.shape[1]
+        dev = depth.device
+        grad_lm = 1 if grad_params is not None else 0
+        lmax, Bp, B2, nu = grad_params if grad_params is not None else (2.0, 1.0, 1.0, 200.0)
+        out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+        tape = torch.empty(ws_bytes("gs_slam_localize_tape_bytes", B, H, W, int(ds), Nmax, int(numiters), grad_lm),
+                           dtype=torch.uint8, device=dev)
+        ws = workspace(ws_bytes("gs_slam_localize_ws_bytes", B, H, W, int(ds), Nmax), dev, "localize")
+        call("gs_slam_localize_taped", ptr(depth), ptr(gV), ptr(K), ptr(prev), B, H, W, int(ds), ptr(mp), ptr(mn),
+             ptr(counts_i32), Nmax, grad_lm, int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp), float(B2),
+             float(nu), ptr(out), ptr(tape), tape.numel(), ptr(ws), ws.numel(), stream())
+        ctx.save_for_backward(prev, mp, mn, tape)
+        ctx.cfg = (B, H, W, int(ds), Nmax, grad_lm, int(numiters), _thresh(dist_thresh), float(lmax), float(Bp), float(B2), float(nu))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        prev, mp, mn, tape = ctx.saved_tensors
+        B, H, W, ds, Nmax, grad_lm, numiters, thresh, lmax, Bp, B2, nu = ctx.cfg
+        dev = prev.device
+        g_out = _f32c(g_out)
+        g_gV = torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev)
+        g_mp = torch.empty_like(mp) if ctx.needs_input_grad[4] else None
+        g_mn = torch.empty_like(mn) if ctx.needs_input_grad[5] else None
+        g_prev = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+        ws = workspace(ws_bytes("gs_slam_localize_backward_ws_bytes", B, H, W, ds, Nmax), dev, "localize_bwd")
+        call("gs_slam_localize_backward", ptr(prev), B, H, W, ds, ptr(mp), ptr(mn), Nmax, grad_lm, numiters, thresh, lmax, Bp, B2,
+             nu, ptr(tape), tape.numel(), ptr(g_out), ptr(g_gV), ptr(g_mp), ptr(g_mn), ptr(g_prev), ptr(ws), ws.numel(), stream())
+        return g_gV, None, None, g_prev, g_mp, g_mn, None, None, None, None, None, None
+
+
+def slam_localize_autograd(gV, depth, K, prev_poses, map_points, map_normals, map_counts_i32, ds, numiters, damp, dist_thresh,
+                           grad_params=None):
+    """Differentiable fused localisation -> poses (B,1,4,4) with grad_fn."""
+    require_hip(gV, depth, K, prev_poses, map_points, map_normals, map_counts_i32, op="slam_localize")
+    return _LocalizeFn.apply(gV, depth, K, prev_poses, map_points, map_normals, map_counts_i32, ds, numiters, damp, dist_thresh,
+                             grad_params)
 
 
 # ---------------------------------------------------------------------------------------------- C / U / F / A

@@ -21,6 +21,10 @@ class ICPSLAM(nn.Module):
     """Point-based SLAM with ICP odometry.  Keyword arguments, defaults, `forward` / `step` contract,
     warnings and errors follow the reference class."""
 
+    # differentiable localisation as one autograd node (gs_slam_localize_taped); False = the staged
+    # formulation with one node per op, kept as an independent check of the fused reverse pass
+    fused_autograd = True
+
     def __init__(self, *, odom: str = "gradicp", dsratio: int = 4, numiters: int = 20, damp: float = 1e-8,
                  dist_thresh: Union[float, int, None] = None, lambda_max: Union[float, int] = 2.0,
                  B: Union[float, int] = 1.0, B2: Union[float, int] = 1.0, nu: Union[float, int] = 200.0,
@@ -111,9 +115,16 @@ class ICPSLAM(nn.Module):
                 or not all(t.is_cuda for t in tensors) or len(pointclouds) != len(live_frame)):
             return None
         mp, mn = pointclouds.points_padded, pointclouds.normals_padded
-        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors + (mp, mn, live_frame.rgb_image)):
-            return None
         gparams = (p.lambda_max, p.B, p.B2, p.nu) if self.odom == "gradicp" else None
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors + (mp, mn)):
+            if not self.fused_autograd:
+                return None  # staged path below: one autograd node per op, like the reference's graph
+            # one autograd node for the whole step; the live frame's maps under the previous pose stay an
+            # ordinary differentiable input so that their adjoint reaches depth / intrinsics / pose
+            live_frame.poses = prev_frame.poses
+            return ops.slam_localize_autograd(live_frame.global_vertex_map, live_frame.depth_image, live_frame.intrinsics,
+                                              prev_frame.poses, mp, mn, pointclouds._counts_i32(), self.dsratio, p.numiters,
+                                              p.damp, p.dist_thresh, gparams)
         poses, V, N = ops.slam_localize_raw(live_frame.depth_image, live_frame.intrinsics, prev_frame.poses, mp, mn,
                                             pointclouds._counts_i32(), self.dsratio, p.numiters, p.damp, p.dist_thresh,
                                             gparams)

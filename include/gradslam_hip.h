@@ -127,13 +127,14 @@ int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max
 
 /* gs_gather_table_rows (points and normals) + gs_bucket_by_pixel fused into five launches: everything
  * gs_icp_point_to_plane needs of its target -- tgt / tgt_normals (B,cap,3) and counts (B) in the reference's
- * order, plus the search hints. */
+ * order, plus the search hints.  tgt_index (B,cap; optional, NULL to skip) receives the map index n of every
+ * target slot (what the reverse pass scatters the target adjoints back with). */
 size_t gs_build_icp_target_ws_bytes(int B, int H, int W, int ds);
 int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H,
                         int W, int ds, const float *map_points, const float *map_normals, int Nmax,
                         int cap, float *tgt, float *tgt_normals, int32_t *counts, float *scan_points,
-                        int32_t *scan_orig, int32_t *pix_start, void *ws, size_t ws_bytes,
-                        gs_stream_t stream);
+                        int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, void *ws,
+                        size_t ws_bytes, gs_stream_t stream);
 
 /* keep mask of downsample_pointclouds' row filter for an arbitrary table
  * (odometry/icputils.py:596-597): mask[i] = rows[i].h % ds == 0 && rows[i].w % ds == 0 */
@@ -229,8 +230,8 @@ int gs_icp_point_to_plane_grad(const float *src, const int32_t *d_ns, int max_ns
  * Forward: same loop and results as gs_icp_point_to_plane[_grad], but every association launch keeps its
  * cloud and neighbour array, and every step its state, in the caller's `tape` (gs_icp_tape_bytes).
  * Backward: given grad_T (device 4x4, adjoint of out_T) walks the tape in reverse on the device with no
- * host synchronisation and writes grad_src (max_ns,3), grad_tgt / grad_normals (max_nt,3; optional, NULL
- * to skip) and grad_init_T (4x4).  grad_lm selects the gradLM variant (0: LM, parameters ignored). */
+ * host synchronisation and writes grad_src (max_ns,3), grad_tgt / grad_normals (max_nt,3, rows < *d_nt;
+ * optional, NULL to skip) and grad_init_T (4x4).  grad_lm selects the gradLM variant (0: LM, parameters ignored). */
 size_t gs_icp_tape_bytes(int max_ns, int numiters, int grad_lm);
 int gs_icp_point_to_plane_taped(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
                                 const float *tgt_normals, const int32_t *d_nt, int max_nt,
@@ -241,12 +242,35 @@ int gs_icp_point_to_plane_taped(const float *src, const int32_t *d_ns, int max_n
                                 gs_stream_t stream);
 size_t gs_icp_backward_ws_bytes(int max_ns);
 int gs_icp_point_to_plane_backward(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
-                                   const float *tgt_normals, int max_nt, const float *init_T,
+                                   const float *tgt_normals, const int32_t *d_nt, int max_nt, const float *init_T,
                                    int numiters, float dist_thresh, int grad_lm, float lambda_max,
                                    float B, float B2, float nu, const void *tape, size_t tape_bytes,
                                    const float *grad_T, float *grad_src, float *grad_tgt,
                                    float *grad_normals, float *grad_init_T, void *ws, size_t ws_bytes,
                                    gs_stream_t stream);
+
+/* ---------------------------------------------------------------- differentiable localisation step
+ * gs_slam_localize with autograd (the same stages; gvertex = the live frame's global vertex map under the
+ * PREVIOUS pose is an input here, so that its own adjoint chains into gs_vertex_normal_maps_backward).
+ * Gradients flow to gvertex (the ICP source cloud), to the map points / normals that were ICP targets, and
+ * to prev_poses through the final composition -- exactly the paths torch autograd follows in the reference
+ * (icpslam.py:238-247): projection / ds-grid selection / association indices are constants.
+ * Backward outputs are dense and fully written: grad_gvertex (B,H,W,3), grad_map_points / grad_map_normals
+ * (B,Nmax,3; optional), grad_prev_poses (B,16). */
+size_t gs_slam_localize_tape_bytes(int B, int H, int W, int ds, int Nmax, int numiters, int use_grad_lm);
+int gs_slam_localize_taped(const float *depth, const float *gvertex, const float *intrinsics,
+                           const float *prev_poses, int B, int H, int W, int ds, const float *map_points,
+                           const float *map_normals, const int32_t *map_counts, int Nmax, int use_grad_lm,
+                           int numiters, float damp, float dist_thresh, float lambda_max, float Bp,
+                           float B2, float nu, float *out_poses, void *tape, size_t tape_bytes, void *ws,
+                           size_t ws_bytes, gs_stream_t stream);
+size_t gs_slam_localize_backward_ws_bytes(int B, int H, int W, int ds, int Nmax);
+int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int ds, const float *map_points,
+                              const float *map_normals, int Nmax, int use_grad_lm, int numiters,
+                              float dist_thresh, float lambda_max, float Bp, float B2, float nu,
+                              const void *tape, size_t tape_bytes, const float *grad_out_poses,
+                              float *grad_gvertex, float *grad_map_points, float *grad_map_normals,
+                              float *grad_prev_poses, void *ws, size_t ws_bytes, gs_stream_t stream);
 
 /* ---------------------------------------------------------------- whole localisation step
  * ICPSLAM._localize for odom in {icp, gradicp} (slam/icpslam.py:238-247) as ONE call with no host

@@ -355,6 +355,32 @@ def test_fused_reverse_pass_matches_unrolled_autograd_at_size(gs):
             assert rel_err(a, b) < 3e-4, (grad_lm, key)  # measured 6e-5
 
 
+@pytest.mark.parametrize("odom", ["icp", "gradicp"])
+def test_fused_differentiable_localisation_matches_staged(gs, odom):
+    """PointFusion over 3 frames at 160x120 with gradients: the one-node localisation (taped device loop,
+    search hints, device-side reverse pass) against the staged per-op autograd graph."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(1, 3, 120, 160, seed=5)
+    res = []
+    for fused in (True, False):
+        cc, d2, kk, pp = (x.to(DEV).clone().requires_grad_(True) for x in (c, dd, K, P))
+        slam = gs.slam.PointFusion(odom=odom, dsratio=2, numiters=6, device=DEV)
+        slam.fused_autograd = fused
+        old, gs.odometry.icputils.FUSED_AUTOGRAD = gs.odometry.icputils.FUSED_AUTOGRAD, fused
+        try:
+            pcs, poses = slam(gs.RGBDImages(cc, d2, kk, pp))
+            (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
+        finally:
+            gs.odometry.icputils.FUSED_AUTOGRAD = old
+        res.append((poses.detach().cpu(), pcs.points_padded.detach().cpu(), [x.grad.cpu() for x in (cc, d2, kk, pp)]))
+    (pa, ma, ga), (pb, mb, gb) = res
+    assert rel_err(pa, pb) < 1e-5 and ma.shape == mb.shape and rel_err(ma, mb) < 1e-5
+    for name, a, b in zip(("colors", "depths", "intrinsics", "poses"), ga, gb):
+        print(odom, name, "rel err %.2e" % rel_err(a, b))
+        assert rel_err(a, b) < 1e-3, name
+
+
 # ------------------------------------------------------------------ P / S / D
 def test_active_points_and_downsample_vs_oracle(gs, golden):
     from oracle import fusion, icp
