@@ -30,6 +30,7 @@ SIGNATURES = {
     "gs_compact_ws_bytes": (c_sz, [c_i64]),
     "gs_compact_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compact_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
+    "gs_expand_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_sz, c_p]),
     "gs_downsample_frame_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "gs_downsample_frame": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_build_icp_target_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

@@ -7,9 +7,18 @@
 // materialising flags.  No inter-workgroup hand-off inside a launch, so no coherence protocol.
 #pragma once
 
+#include <type_traits>
+
 #include "gs_common.hpp"
 
 namespace gs {
+
+// a Writer may also provide skip(i), called for every row the predicate rejects (used by the adjoint of a
+// compaction, which must write zeros there)
+template <class W, class = void>
+struct writer_has_skip : std::false_type {};
+template <class W>
+struct writer_has_skip<W, std::void_t<decltype(&W::skip)>> : std::true_type {};
 
 constexpr int kCT = 256;               // threads per block
 constexpr int kCI = 4;                 // consecutive items per thread
@@ -79,6 +88,8 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
         if (f[k]) {
             writer(base + k, (int64_t)pos);
             ++pos;
+        } else if constexpr (writer_has_skip<Writer>::value) {
+            if (base + k < n) writer.skip(base + k);
         }
     }
 }

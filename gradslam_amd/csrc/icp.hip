@@ -1132,11 +1132,12 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
 
 // ------------------------------------------------------------------ reverse pass of the taped loops
 // Walks the tape backwards entirely on the device (accept/reject is read from the records, so rejected LM
-// iterations cost three empty launches and no host round trip).  Per iteration:
-//   A  sums_k   : sum_i gP_i (x) s_i , sum_i gP_i      (adjoint of  s' = dT s  with respect to dT)
+// iterations cost two empty launches and no host round trip).  Per iteration:
 //   S  small_k  : adjoints of T' = dT T, dT = exp(xi), xi = (H + damp I)^-1 g, and of the gradLM gates
 //   B  look_k   : gradLM only -- adjoint of the look-ahead error
-//   C  lin_k    : gP_i <- R^T gP_i + adjoint of the linearisation (H, g, e) at s_i
+//   C  lin_k    : gP_i <- R^T gP_i + adjoint of the linearisation (H, g, e) at s_i ; and, for the step that
+//                 produced s from its predecessor cloud q (s = dT q):  sum_i gP_i (x) q_i , sum_i gP_i
+//                 -- what the S kernel of that earlier step needs as the adjoint of dT
 // gP (ns,3) is updated in place, target / normal adjoints accumulate with float atomics.
 constexpr int BWD_T = 256;
 constexpr int BWD_MAXB = 512;
@@ -1151,6 +1152,7 @@ struct BwdState {
     float g_new_err, g_err, gdamp;
     int active;      // 0: rejected LM iteration, nothing to do
     int src_slot, nn_slot, look_slot;
+    int prev_slot;   // slot of the cloud src_slot was derived from (-1: the caller's source cloud)
 };
 
 __device__ __forceinline__ const IcpState *rec_state(const float *rec) { return reinterpret_cast<const IcpState *>(rec + REC_STATE); }
@@ -1213,22 +1215,6 @@ __device__ __forceinline__ f3 rot_t(const float *R, const f3 g) {  // R^T g, R r
     return f3{R[0] * g.x + R[3] * g.y + R[6] * g.z, R[1] * g.x + R[4] * g.y + R[7] * g.z, R[2] * g.x + R[5] * g.y + R[8] * g.z};
 }
 
-// A: adjoint of (cloud' = dT . cloud) with respect to dT, cloud = the iteration's source slot
-__global__ __launch_bounds__(BWD_T) void bwd_sums_k(const float *__restrict__ rec, LoopBufs B, const float *__restrict__ user_src,
-                                                    const int32_t *__restrict__ d_ns, const float *__restrict__ gP,
-                                                    float *__restrict__ partials) {
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
-    const bool active = rec ? rec[REC_ACCEPT] != 0.0f : true;
-    if (active) {
-        const float *src = rec ? B.P(rec_state(rec)->p_cur) : user_src;
-        const int ns = *d_ns;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) acc_outer(acc, ld3(gP, i), ld3(src, i));
-    }
-    block_store12(acc, partials);
-}
-
 // B (gradLM): adjoint of new_err = e(look, NN(look)); gP_i <- R2^T gP_i + R1^T glook_i ; sums glook (x) s
 __global__ __launch_bounds__(BWD_T) void bwd_look_k(const BwdState *__restrict__ Sb, LoopBufs B, const int32_t *__restrict__ d_ns,
                                                     const float *__restrict__ tgt, const float *__restrict__ nrm, float thresh,
@@ -1257,20 +1243,27 @@ __global__ __launch_bounds__(BWD_T) void bwd_look_k(const BwdState *__restrict__
     block_store12(acc, partials);
 }
 
-// C: gP_i <- (rotate ? R2^T gP_i : gP_i) + adjoint of (H, g, e) at the iteration's source cloud
+// C: gP_i <- (rotate ? R2^T gP_i : gP_i) + adjoint of (H, g, e) at the iteration's source cloud; sums of
+// gP (x) predecessor cloud for the S kernel of the step that made this cloud
 __global__ __launch_bounds__(BWD_T) void bwd_lin_k(const BwdState *__restrict__ Sb, int rotate, LoopBufs B,
+                                                   const float *__restrict__ user_src,
                                                    const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
                                                    const float *__restrict__ nrm, float thresh, float *__restrict__ gP,
-                                                   float *__restrict__ g_tgt, float *__restrict__ g_nrm) {
-    if (!Sb->active) return;
+                                                   float *__restrict__ g_tgt, float *__restrict__ g_nrm,
+                                                   float *__restrict__ partials) {
+    if (!Sb->active) return;  // rejected LM iteration: gP and the pending sums stay as they are
     __shared__ float G[44];
     __shared__ float R[9];
     if (threadIdx.x < 44) G[threadIdx.x] = Sb->G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 73) R[threadIdx.x - 64] = Sb->R2[threadIdx.x - 64];
     __syncthreads();
     const float *src = B.P(Sb->src_slot);
+    const float *prev = Sb->prev_slot >= 0 ? B.P(Sb->prev_slot) : user_src;
     const unsigned long long *nn = B.N(Sb->nn_slot);
     const int ns = *d_ns;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
         const Row r = make_row(src, tgt, nrm, nn, i, ns, thresh);
         f3 g = ld3(gP, i);
@@ -1280,7 +1273,9 @@ __global__ __launch_bounds__(BWD_T) void bwd_lin_k(const BwdState *__restrict__ 
             g.x += sb.x; g.y += sb.y; g.z += sb.z;
         }
         st3(gP, i, g);
+        acc_outer(acc, g, ld3(prev, i));
     }
+    block_store12(acc, partials);
 }
 
 // last: through src0 = init_T . user_src
@@ -1339,11 +1334,22 @@ __device__ void se3_exp_bwd(const float *xi, const double *gT, double *gxi) {
     gxi[3] = gw[0]; gxi[4] = gw[1]; gxi[5] = gw[2];
 }
 
-// sum of the 12-wide partial rows, one thread per sum (nblocks <= BWD_MAXB)
+// sum of the 12-wide partial rows by a 256-thread block: 16 groups stride over the rows, then 12 threads
+// add the 16 group sums in order (nblocks <= BWD_MAXB)
+constexpr int BWD_ST = 256;
 __device__ __forceinline__ void reduce12(const float *__restrict__ partials, int nblocks, float *out_sm) {
+    __shared__ float stage[12][17];
+    const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+    if (k < 12) {
+        float v = 0.0f;
+        for (int b = g; b < nblocks; b += 16) v += partials[b * 12 + k];
+        stage[k][g] = v;
+    }
+    __syncthreads();
     if (threadIdx.x < 12) {
         float v = 0.0f;
-        for (int b = 0; b < nblocks; ++b) v += partials[b * 12 + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += stage[threadIdx.x][q];
         out_sm[threadIdx.x] = v;
     }
     __syncthreads();
@@ -1387,8 +1393,8 @@ __global__ void bwd_init_k(BwdState *Sb, const float *__restrict__ grad_T) {
 }
 
 // S for one LM iteration (record = the STEP_LM record of that iteration)
-__global__ __launch_bounds__(64) void bwd_small_lm_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
-                                                     int nblocks) {
+__global__ __launch_bounds__(BWD_ST) void bwd_small_lm_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
+                                                     int nblocks, int iter) {
     __shared__ float sums[12];
     reduce12(partials, nblocks, sums);
     if (threadIdx.x != 0) return;
@@ -1404,12 +1410,19 @@ __global__ __launch_bounds__(64) void bwd_small_lm_k(BwdState *Sb, const float *
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) Sb->R2[3 * i + j] = S->dT[4 * i + j];
     Sb->src_slot = S->p_cur; Sb->nn_slot = S->b_cur; Sb->look_slot = (int)rec[REC_SLOT];
+    // the cloud of this iteration was made by the closest earlier accepted iteration (from ITS cloud)
+    int prev = -1;
+    for (int j = iter - 1; j >= 0 && prev < 0; --j) {
+        const float *rj = rec - (size_t)(iter - j) * REC_WORDS;
+        if (rj[REC_ACCEPT] != 0.0f) prev = rec_state(rj)->p_cur;
+    }
+    Sb->prev_slot = prev;
     Sb->active = 1;
 }
 
 // S1 for one gradLM iteration (record = its STEP_GRAD_B record; the next record's head = the state after)
-__global__ __launch_bounds__(64) void bwd_small_g1_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
-                                                     int nblocks, GradParams gp) {
+__global__ __launch_bounds__(BWD_ST) void bwd_small_g1_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
+                                                     int nblocks, GradParams gp, int prev_slot) {
     __shared__ float sums[12];
     reduce12(partials, nblocks, sums);
     if (threadIdx.x != 0) return;
@@ -1440,11 +1453,12 @@ __global__ __launch_bounds__(64) void bwd_small_g1_k(BwdState *Sb, const float *
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) { Sb->R2[3 * i + j] = Sn->dT[4 * i + j]; Sb->R1[3 * i + j] = S->dT[4 * i + j]; }
     Sb->src_slot = S->p_cur; Sb->nn_slot = S->b_cur; Sb->look_slot = (int)rec[REC_SLOT];
+    Sb->prev_slot = prev_slot;
     Sb->active = 1;
 }
 
 // S2: look-ahead step dT1 = exp(xi) -> xi ; then the solve
-__global__ __launch_bounds__(64) void bwd_small_g2_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
+__global__ __launch_bounds__(BWD_ST) void bwd_small_g2_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
                                                      int nblocks) {
     __shared__ float sums[12];
     reduce12(partials, nblocks, sums);
@@ -1460,7 +1474,7 @@ __global__ __launch_bounds__(64) void bwd_small_g2_k(BwdState *Sb, const float *
 }
 
 // adjoint of init_T: the T chain starts at init_T and src0 = init_T . user_src
-__global__ __launch_bounds__(64) void bwd_small_end_k(const BwdState *Sb, const float *__restrict__ partials, int nblocks,
+__global__ __launch_bounds__(BWD_ST) void bwd_small_end_k(const BwdState *Sb, const float *__restrict__ partials, int nblocks,
                                                       float *__restrict__ g_init_T) {
     __shared__ float sums[12];
     reduce12(partials, nblocks, sums);
@@ -1506,27 +1520,29 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
     bwd_ws_layout(max_ns, ws, &w);
     const int nb = min(cdiv(max_ns, BWD_T), BWD_MAXB);
     GS_HIP(hipMemsetAsync(w.gP, 0, (size_t)max_ns * 12, st), name);
+    GS_HIP(hipMemsetAsync(w.partials, 0, (size_t)nb * 12 * 4, st), name);  // nothing depends on the final cloud
     if (g_tgt || g_nrm)  // only the rows that exist (max_nt may be a generous capacity)
         hipLaunchKernelGGL(zero_rows_k, dim3(min(cdiv(3 * max_nt, 256), 1024)), dim3(256), 0, st, g_tgt, g_nrm, d_nt, max_nt);
     hipLaunchKernelGGL(bwd_init_k, dim3(1), dim3(64), 0, st, w.S, grad_T);
     for (int k = numiters - 1; k >= 0; --k) {
         if (!grad) {
             const float *rec = tp.rec + (size_t)(1 + k) * REC_WORDS;
-            hipLaunchKernelGGL(bwd_sums_k, dim3(nb), dim3(BWD_T), 0, st, rec, tp.B, src, d_ns, w.gP, w.partials);
-            hipLaunchKernelGGL(bwd_small_lm_k, dim3(1), dim3(64), 0, st, w.S, rec, w.partials, nb);
-            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 1, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm);
+            hipLaunchKernelGGL(bwd_small_lm_k, dim3(1), dim3(BWD_ST), 0, st, w.S, rec, w.partials, nb, k);
+            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 1, tp.B, src, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
+                               w.partials);
         } else {
             const float *rec = tp.rec + (size_t)(1 + 2 * k) * REC_WORDS;
-            hipLaunchKernelGGL(bwd_sums_k, dim3(nb), dim3(BWD_T), 0, st, rec, tp.B, src, d_ns, w.gP, w.partials);
-            hipLaunchKernelGGL(bwd_small_g1_k, dim3(1), dim3(64), 0, st, w.S, rec, w.partials, nb, gp);
+            // slots of the gradLM loop are fixed: cloud k lives in slot 0 (k = 0) or 2k
+            hipLaunchKernelGGL(bwd_small_g1_k, dim3(1), dim3(BWD_ST), 0, st, w.S, rec, w.partials, nb, gp,
+                               k == 0 ? -1 : (k == 1 ? 0 : 2 * (k - 1)));
             hipLaunchKernelGGL(bwd_look_k, dim3(nb), dim3(BWD_T), 0, st, w.S, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
                                w.partials);
-            hipLaunchKernelGGL(bwd_small_g2_k, dim3(1), dim3(64), 0, st, w.S, rec, w.partials, nb);
-            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 0, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm);
+            hipLaunchKernelGGL(bwd_small_g2_k, dim3(1), dim3(BWD_ST), 0, st, w.S, rec, w.partials, nb);
+            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 0, tp.B, src, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
+                               w.partials);
         }
     }
-    hipLaunchKernelGGL(bwd_sums_k, dim3(nb), dim3(BWD_T), 0, st, (const float *)nullptr, tp.B, src, d_ns, w.gP, w.partials);
-    hipLaunchKernelGGL(bwd_small_end_k, dim3(1), dim3(64), 0, st, w.S, w.partials, nb, g_init_T);
+    hipLaunchKernelGGL(bwd_small_end_k, dim3(1), dim3(BWD_ST), 0, st, w.S, w.partials, nb, g_init_T);
     hipLaunchKernelGGL(bwd_finish_k, dim3(nb), dim3(BWD_T), 0, st, init_T, d_ns, w.gP, g_src);
     GS_LAUNCH_CHECK(name);
     return GS_OK;

@@ -122,12 +122,14 @@ __global__ __launch_bounds__(TW *TH) void vertex_normal_k(const float *__restric
 // pass 1: per pixel, adjoint of the normal w.r.t. its two difference vectors -> ws (dh_bar, dv_bar);
 //         also accumulates d/dR from the global normal map.
 // pass 2: per pixel, gather the stencil adjoints, add the vertex adjoints, reduce to depth / K / pose.
+constexpr int VN_PART = 25;  // pass 2: R_bar(9) t_bar(3) a,c,e,f_bar(4) ; pass 1: R_bar(9) from the normals
+
 __global__ __launch_bounds__(256) void vn_bwd_pass1_k(const float *__restrict__ depth, const float *__restrict__ Ks,
                                                       const float *__restrict__ poses, int L, int H, int W,
                                                       const float *__restrict__ g_normal,
                                                       const float *__restrict__ g_gnormal,
                                                       float *__restrict__ dhb, float *__restrict__ dvb,
-                                                      float *__restrict__ g_poses) {
+                                                      float *__restrict__ part /* [bl][block][VN_PART] */) {
     const int bl = blockIdx.y;
     const int b = bl / L;
     const int64_t HW = (int64_t)H * W;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void vn_bwd_pass1_k(const float *__restrict__ 
         st3(dhb, pix, f3{dv.y * cb.z - dv.z * cb.y, dv.z * cb.x - dv.x * cb.z, dv.x * cb.y - dv.y * cb.x});
         st3(dvb, pix, f3{cb.y * dh.z - cb.z * dh.y, cb.z * dh.x - cb.x * dh.z, cb.x * dh.y - cb.y * dh.x});
     }
-    if (g_gnormal && poses && g_poses) {
+    {   // per-block partial sums; vn_bwd_final_k adds them up (no same-address atomics, fixed order)
         __shared__ float sm[4][9];
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -195,11 +197,9 @@ __global__ __launch_bounds__(256) void vn_bwd_pass1_k(const float *__restrict__ 
             if (lane == 0) sm[wid][i] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 9) {
-            const float v = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-            const int r = threadIdx.x / 3, cidx = threadIdx.x % 3;
-            atomicAdd(g_poses + 16 * (int64_t)bl + 4 * r + cidx, v);
-        }
+        if (threadIdx.x < 9)
+            part[((int64_t)bl * gridDim.x + blockIdx.x) * VN_PART + 16 + threadIdx.x] =
+                sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
     }
 }
 
@@ -208,8 +208,7 @@ __global__ __launch_bounds__(256) void vn_bwd_pass2_k(const float *__restrict__ 
                                                       const float *__restrict__ g_vertex,
                                                       const float *__restrict__ g_gvertex,
                                                       const float *__restrict__ dhb, const float *__restrict__ dvb,
-                                                      float *__restrict__ g_depth, float *__restrict__ g_K,
-                                                      float *__restrict__ g_poses) {
+                                                      float *__restrict__ g_depth, float *__restrict__ part) {
     const int bl = blockIdx.y;
     const int b = bl / L;
     const int64_t HW = (int64_t)H * W;
@@ -278,24 +277,44 @@ __global__ __launch_bounds__(256) void vn_bwd_pass2_k(const float *__restrict__ 
         if (lane == 0) sm[wid][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 16)
+        part[((int64_t)bl * gridDim.x + blockIdx.x) * VN_PART + threadIdx.x] =
+            sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// one block per (b,l): adds the per-block partials up and applies them to the pose / intrinsics adjoints
+__global__ __launch_bounds__(256) void vn_bwd_final_k(const float *__restrict__ part, int nblocks, int have_pass1,
+                                                      const float *__restrict__ Ks, const float *__restrict__ poses, int L,
+                                                      float *__restrict__ g_K, float *__restrict__ g_poses) {
+    __shared__ float stage[VN_PART][9];
+    __shared__ float tot[VN_PART];
+    const int bl = blockIdx.x, b = bl / L;
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // 8 groups
+    float v = 0.0f;
+    if (k < VN_PART && (k < 16 || have_pass1))
+        for (int i = g; i < nblocks; i += 8) v += part[((int64_t)bl * nblocks + i) * VN_PART + k];
+    if (k < VN_PART) stage[k][g] = v;
+    __syncthreads();
+    if (threadIdx.x < VN_PART) {
+        float t = 0.0f;
+        for (int q = 0; q < 8; ++q) t += stage[threadIdx.x][q];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12 && g_poses && poses) {
         const int i = threadIdx.x;
-        const float v = sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i];
-        if (i < 12) {
-            if (g_poses && poses && v != 0.0f) {
-                const int slot = (i < 9) ? 4 * (i / 3) + (i % 3) : 4 * (i - 9) + 3;
-                atomicAdd(g_poses + 16 * (int64_t)bl + slot, v);
-            }
-        } else if (g_K && v != 0.0f) {
-            // a = 1/(fx+eps), c = -cx/(fx+eps), e = 1/(fy+eps), f = -cy/(fy+eps)
-            const float *K = Ks + 16 * b;
-            const float fx = K[0] + 1e-6f, fy = K[5] + 1e-6f;
-            float *gk = g_K + 16 * b;
-            if (i == 12) atomicAdd(gk + 0, -v / (fx * fx));
-            if (i == 13) { atomicAdd(gk + 0, v * K[2] / (fx * fx)); atomicAdd(gk + 2, -v / fx); }
-            if (i == 14) atomicAdd(gk + 5, -v / (fy * fy));
-            if (i == 15) { atomicAdd(gk + 5, v * K[6] / (fy * fy)); atomicAdd(gk + 6, -v / fy); }
-        }
+        const int slot = (i < 9) ? 4 * (i / 3) + (i % 3) : 4 * (i - 9) + 3;
+        g_poses[16 * (int64_t)bl + slot] += tot[i] + (i < 9 ? tot[16 + i] : 0.0f);
+    }
+    if (threadIdx.x == 32 && g_K) {
+        // a = 1/(fx+eps), c = -cx/(fx+eps), e = 1/(fy+eps), f = -cy/(fy+eps)
+        const float *K = Ks + 16 * b;
+        const float fx = K[0] + 1e-6f, fy = K[5] + 1e-6f;
+        float *gk = g_K + 16 * b;  // L frames share one K: atomics (L per address)
+        atomicAdd(gk + 0, -tot[12] / (fx * fx) + tot[13] * K[2] / (fx * fx));
+        atomicAdd(gk + 2, -tot[13] / fx);
+        atomicAdd(gk + 5, -tot[14] / (fy * fy) + tot[15] * K[6] / (fy * fy));
+        atomicAdd(gk + 6, -tot[15] / fy);
     }
 }
 
@@ -375,6 +394,30 @@ struct MultiWriter {
     }
 };
 
+// adjoint of MultiWriter: row i of every output = the compacted row it went to, or zero
+struct ExpandWriter {
+    const uint32_t *g[4];
+    uint32_t *out[4];
+    int words[4];
+    int n_arrays;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a >= n_arrays) break;
+            const int w = words[a];
+            for (int k = 0; k < w; ++k) out[a][i * w + k] = g[a][pos * w + k];
+        }
+    }
+    __device__ void skip(int64_t i) const {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a >= n_arrays) break;
+            const int w = words[a];
+            for (int k = 0; k < w; ++k) out[a][i * w + k] = 0u;
+        }
+    }
+};
+
 }  // namespace gs
 
 using namespace gs;
@@ -397,7 +440,8 @@ int gs_vertex_normal_maps(const float *depth, const float *intrinsics, const flo
 }
 
 size_t gs_vertex_normal_maps_backward_ws_bytes(int B, int L, int H, int W) {
-    return align_up((size_t)B * L * H * W * 3 * sizeof(float), 256) * 2;
+    return align_up((size_t)B * L * H * W * 3 * sizeof(float), 256) * 2 +
+           align_up((size_t)B * L * cdiv((int64_t)H * W, 256) * VN_PART * sizeof(float), 256);
 }
 
 int gs_vertex_normal_maps_backward(const float *depth, const float *intrinsics, const float *poses, int B, int L, int H,
@@ -411,19 +455,24 @@ int gs_vertex_normal_maps_backward(const float *depth, const float *intrinsics, 
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W;
     dim3 grid(cdiv(HW, 256), B * L);
+    if (ws_bytes < gs_vertex_normal_maps_backward_ws_bytes(B, L, H, W) || !ws) {
+        set_error("gs_vertex_normal_maps_backward: workspace too small");
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    const size_t map_b = align_up((size_t)B * L * HW * 3 * sizeof(float), 256);
+    float *part = (float *)((char *)ws + 2 * map_b);
     if (need_n) {
-        if (ws_bytes < gs_vertex_normal_maps_backward_ws_bytes(B, L, H, W) || !ws) {
-            set_error("gs_vertex_normal_maps_backward: workspace too small");
-            return GS_ERR_WORKSPACE_TOO_SMALL;
-        }
         dhb = (float *)ws;
-        dvb = (float *)((char *)ws + align_up((size_t)B * L * HW * 3 * sizeof(float), 256));
+        dvb = (float *)((char *)ws + map_b);
         hipLaunchKernelGGL(vn_bwd_pass1_k, grid, dim3(256), 0, st, depth, intrinsics, poses, L, H, W, g_normal,
-                           g_gnormal, dhb, dvb, g_poses);
+                           g_gnormal, dhb, dvb, part);
         GS_LAUNCH_CHECK("gs_vertex_normal_maps_backward/1");
     }
     hipLaunchKernelGGL(vn_bwd_pass2_k, grid, dim3(256), 0, st, depth, intrinsics, poses, L, H, W, g_vertex, g_gvertex,
-                       dhb, dvb, g_depth, g_intrinsics, g_poses);
+                       dhb, dvb, g_depth, part);
+    if (g_intrinsics || (g_poses && poses))
+        hipLaunchKernelGGL(vn_bwd_final_k, dim3(B * L), dim3(256), 0, st, part, (int)grid.x, need_n ? 1 : 0, intrinsics, poses, L,
+                           g_intrinsics, g_poses);
     GS_LAUNCH_CHECK("gs_vertex_normal_maps_backward/2");
     return GS_OK;
 }
@@ -482,6 +531,26 @@ int gs_compact_multi(int n_arrays, const float *const *h_src, const int *h_row_f
     }
     MaskPred pred{mask};
     return compact_launch(n_rows, pred, wr, out_count, ws, (hipStream_t)stream, "gs_compact_multi");
+}
+
+int gs_expand_multi(int n_arrays, const float *const *h_grad, const int *h_row_floats, float *const *h_out,
+                    const uint8_t *mask, int64_t n_rows, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(n_arrays >= 1 && n_arrays <= 4 && h_grad && h_row_floats && h_out && mask && n_rows >= 0,
+               "gs_expand_multi: bad arguments (1..4 arrays)");
+    if (ws_bytes < compact_ws_bytes(n_rows) || !ws) {
+        set_error("gs_expand_multi: workspace too small (%zu < %zu)", ws_bytes, compact_ws_bytes(n_rows));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    ExpandWriter wr;
+    wr.n_arrays = n_arrays;
+    for (int a = 0; a < 4; ++a) {
+        wr.g[a] = a < n_arrays ? (const uint32_t *)h_grad[a] : nullptr;
+        wr.out[a] = a < n_arrays ? (uint32_t *)h_out[a] : nullptr;
+        wr.words[a] = a < n_arrays ? h_row_floats[a] : 0;
+        GS_REQUIRE(a >= n_arrays || (h_grad[a] && h_out[a] && h_row_floats[a] > 0), "gs_expand_multi: NULL array %d", a);
+    }
+    MaskPred pred{mask};
+    return compact_launch(n_rows, pred, wr, (int *)nullptr, ws, (hipStream_t)stream, "gs_expand_multi");
 }
 
 size_t gs_downsample_frame_ws_bytes(int H, int W, int ds) {

@@ -160,6 +160,54 @@ class _MaskSelectFn(torch.autograd.Function):
         return out, None
 
 
+class _MultiMaskSelectFn(torch.autograd.Function):
+    """[x[mask] for x in xs] for up to 4 (n, C_a) arrays sharing one mask: one compaction (one scan, one host
+    sync for the length) forward, one expansion kernel backward."""
+
+    @staticmethod
+    def forward(ctx, mask, *xs):
+        outs, cnt = compact_multi_raw(list(xs), mask)
+        n = int(cnt.item())
+        ctx.save_for_backward(mask)
+        ctx.shapes = [x.shape for x in xs]
+        return tuple(o[:n] for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+
+        (mask,) = ctx.saved_tensors
+        n = mask.shape[0]
+        gs = [_f32c(g) for g in gs]
+        dev = mask.device
+        outs = [torch.empty(shape, dtype=torch.float32, device=dev) for shape in ctx.shapes]
+        if n == 0:
+            return (None, *outs)
+        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous()
+        k = len(gs)
+        # an empty selection leaves nothing to read: give the kernel a valid (unused) pointer
+        a_g = (ctypes.c_void_p * k)(*[(g if g.numel() else o).data_ptr() for g, o in zip(gs, outs)])
+        a_out = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs])
+        a_w = (ctypes.c_int * k)(*[o.numel() // n for o in outs])
+        ws = workspace(ws_bytes("gs_compact_ws_bytes", n), dev, "compact")
+        call("gs_expand_multi", k, a_g, a_w, a_out, ptr(m8), n, ptr(ws), ws.numel(), stream())
+        return (None, *outs)
+
+
+def mask_select_multi(xs, mask: torch.Tensor):
+    """[x[mask] for x in xs] (<= 4 arrays, (n, C_a) float32 each), differentiable, one scan and one sync."""
+    return list(_MultiMaskSelectFn.apply(mask, *xs))
+
+
+def select_rows_multi(xs, mask: torch.Tensor):
+    """[x[mask] for x in xs] with or without autograd: one compaction, one host sync either way."""
+    if torch.is_grad_enabled() and any(x.requires_grad for x in xs):
+        return mask_select_multi(xs, mask)
+    outs, cnt = compact_multi_raw(list(xs), mask)
+    n = int(cnt.item())
+    return [o[:n] for o in outs]
+
+
 def mask_select(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     if torch.is_grad_enabled() and x.requires_grad:
         return _MaskSelectFn.apply(x, mask)

@@ -259,9 +259,9 @@ def fuse_with_map(pointclouds: Pointclouds, rgbdimages: RGBDImages, pc2im_bnhw: 
     grad_mode = torch.is_grad_enabled() and any(t.requires_grad for t in (vertex_maps, normal_maps, rgb_image, alpha_image))
     flat = lambda x, b, c: x[b].reshape(-1, c)
     if grad_mode:
-        sel = lambda x, b, c: ops.mask_select(flat(x, b, c), mask[b].reshape(-1))
-        new = [[sel(vertex_maps, b, 3) for b in range(B)], [sel(normal_maps, b, 3) for b in range(B)],
-               [sel(rgb_image, b, 3) for b in range(B)], [sel(alpha_image, b, 1) for b in range(B)]]
+        per_b = [ops.mask_select_multi([flat(vertex_maps, b, 3), flat(normal_maps, b, 3), flat(rgb_image, b, 3),
+                                        flat(alpha_image, b, 1)], mask[b].reshape(-1)) for b in range(B)]
+        new = [[per_b[b][a] for b in range(B)] for a in range(4)]
     else:
         bufs, cnts = [], []
         for b in range(B):

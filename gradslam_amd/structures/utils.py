@@ -22,6 +22,6 @@ def pointclouds_from_rgbdimages(rgbdimages: RGBDImages, *, global_coordinates: b
         return Pointclouds(points=vmap.reshape(B, -1, 3).contiguous(), normals=nmap.reshape(B, -1, 3).contiguous(),
                            colors=rgb.reshape(B, -1, 3).contiguous())
     mask = rgbdimages.valid_depth_mask.squeeze(-1)  # (B,1,H,W)
-    sel = lambda x, b: ops.mask_select(x[b].reshape(-1, 3), mask[b].reshape(-1))
-    return Pointclouds(points=[sel(vmap, b) for b in range(B)], normals=[sel(nmap, b) for b in range(B)],
-                       colors=[sel(rgb, b) for b in range(B)])
+    per_b = [ops.select_rows_multi([vmap[b].reshape(-1, 3), nmap[b].reshape(-1, 3), rgb[b].reshape(-1, 3)],
+                                   mask[b].reshape(-1)) for b in range(B)]
+    return Pointclouds(points=[p[0] for p in per_b], normals=[p[1] for p in per_b], colors=[p[2] for p in per_b])

@@ -80,6 +80,11 @@ int gs_compact_rows(const float *src, const uint8_t *mask, int64_t n_rows, int r
 int gs_compact_multi(int n_arrays, const float *const *h_src, const int *h_row_floats,
                      float *const *h_out, const uint8_t *mask, int64_t n_rows, int32_t *out_count,
                      void *ws, size_t ws_bytes, gs_stream_t stream);
+/* Adjoint of gs_compact_multi (what autograd does for x[mask] in the reference): h_out[a] (n_rows, w_a)
+ * receives the compacted adjoint row of every selected row and zeros everywhere else. */
+int gs_expand_multi(int n_arrays, const float *const *h_grad, const int *h_row_floats,
+                    float *const *h_out, const uint8_t *mask, int64_t n_rows, void *ws, size_t ws_bytes,
+                    gs_stream_t stream);
 
 /* ---------------------------------------------------------------- D: live frame -> ICP source cloud
  * downsample_rgbdimages (odometry/icputils.py:651-669): [::ds, ::ds] sub-grid of the global
