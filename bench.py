@@ -128,9 +128,27 @@ def aux_pointfusion(gs, dev, raw, n_frames=30):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     err = float((poses.cpu() - P).abs().max())
-    return {"pointfusion_c3_forward_fps": round(n_frames / dt, 2), "frames": n_frames,
-            "final_map_points": int(pcs.num_points_per_pointcloud.item()), "pose_max_abs_err_vs_gt": round(err, 5),
-            "note": "PointFusion(odom='icp') forward over a 640x480 synthetic sequence, not part of `value`"}
+    out = {"pointfusion_c3_forward_fps": round(n_frames / dt, 2), "frames": n_frames,
+           "final_map_points": int(pcs.num_points_per_pointcloud.item()), "pose_max_abs_err_vs_gt": round(err, 5),
+           "note": "PointFusion(odom='icp') forward over a 640x480 synthetic sequence, not part of `value`"}
+    # forward + backward (BASELINE configs[2] asks for both), default odometry = gradicp, loss as in the golden vectors
+    for rep in range(2):  # first pass warms the allocator
+        leaves = [x.to(dev).clone().requires_grad_(True) for x in (c, d, K, P)]
+        slam = gs.slam.PointFusion(odom="gradicp", dsratio=DS, numiters=ITERS, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pcs, poses = slam(gs.RGBDImages(*leaves))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        finite = all(bool(torch.isfinite(x.grad).all()) for x in leaves)
+        del pcs, poses
+    out.update({"pointfusion_c3_gradicp_fwd_ms_per_frame": round(1e3 * (t1 - t0) / n_frames, 3),
+                "pointfusion_c3_gradicp_bwd_ms_per_frame": round(1e3 * (t2 - t1) / n_frames, 3),
+                "pointfusion_c3_gradicp_fwd_bwd_fps": round(n_frames / (t2 - t0), 2), "grads_finite": finite})
+    return out
 
 
 def cpu_baseline(raw, n_frames=24):

@@ -283,21 +283,24 @@ __global__ __launch_bounds__(256) void vn_bwd_pass2_k(const float *__restrict__ 
 }
 
 // one block per (b,l): adds the per-block partials up and applies them to the pose / intrinsics adjoints
-__global__ __launch_bounds__(256) void vn_bwd_final_k(const float *__restrict__ part, int nblocks, int have_pass1,
+__global__ __launch_bounds__(1024) void vn_bwd_final_k(const float *__restrict__ part, int nblocks, int have_pass1,
                                                       const float *__restrict__ Ks, const float *__restrict__ poses, int L,
                                                       float *__restrict__ g_K, float *__restrict__ g_poses) {
-    __shared__ float stage[VN_PART][9];
+    __shared__ float stage[VN_PART][33];
     __shared__ float tot[VN_PART];
     const int bl = blockIdx.x, b = bl / L;
-    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // 8 groups
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // 32 groups
     float v = 0.0f;
-    if (k < VN_PART && (k < 16 || have_pass1))
-        for (int i = g; i < nblocks; i += 8) v += part[((int64_t)bl * nblocks + i) * VN_PART + k];
+    if (k < VN_PART && (k < 16 || have_pass1)) {
+#pragma unroll 4
+        for (int i = g; i < nblocks; i += 32) v += part[((int64_t)bl * nblocks + i) * VN_PART + k];
+    }
     if (k < VN_PART) stage[k][g] = v;
     __syncthreads();
     if (threadIdx.x < VN_PART) {
         float t = 0.0f;
-        for (int q = 0; q < 8; ++q) t += stage[threadIdx.x][q];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t += stage[threadIdx.x][q];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
@@ -471,7 +474,7 @@ int gs_vertex_normal_maps_backward(const float *depth, const float *intrinsics, 
     hipLaunchKernelGGL(vn_bwd_pass2_k, grid, dim3(256), 0, st, depth, intrinsics, poses, L, H, W, g_vertex, g_gvertex,
                        dhb, dvb, g_depth, part);
     if (g_intrinsics || (g_poses && poses))
-        hipLaunchKernelGGL(vn_bwd_final_k, dim3(B * L), dim3(256), 0, st, part, (int)grid.x, need_n ? 1 : 0, intrinsics, poses, L,
+        hipLaunchKernelGGL(vn_bwd_final_k, dim3(B * L), dim3(1024), 0, st, part, (int)grid.x, need_n ? 1 : 0, intrinsics, poses, L,
                            g_intrinsics, g_poses);
     GS_LAUNCH_CHECK("gs_vertex_normal_maps_backward/2");
     return GS_OK;

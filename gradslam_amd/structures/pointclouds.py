@@ -129,7 +129,11 @@ class Pointclouds(object):
         """int32 device copy of the per-batch counts, the form the kernels read (cached)."""
         cached = getattr(self, "_counts_i32_cache", None)
         if cached is None or cached[0] != self._counts:
-            cached = (list(self._counts), torch.tensor(self._counts, dtype=torch.int32, device=self.device))
+            if len(self._counts) == 1:  # filled by a kernel: no pageable host->device copy on the frame path
+                dev_counts = torch.full((1,), int(self._counts[0]), dtype=torch.int32, device=self.device)
+            else:
+                dev_counts = torch.tensor(self._counts, dtype=torch.int32, device=self.device)
+            cached = (list(self._counts), dev_counts)
             self._counts_i32_cache = cached
         return cached[1]
 
