@@ -633,3 +633,40 @@ def test_full_size_properties(gs):
     d2, idx = gs.ops.knn1_unpack(gs.ops.knn1_raw(pts, pts))
     dup_ok = (pts[idx] == pts).all(1)
     assert (d2 == 0).all() and dup_ok.all() and (idx <= torch.arange(20000, device=DEV)).all()
+
+
+def test_config5_shape_batch_independence_and_pose_gradients(gs):
+    """BASELINE configs[4] shape: ICPSLAM (gradicp) on 1296x968 depth, batch 4, L=3.  Properties that need no
+    oracle at this size: (1) sequences are independent -- the batched run equals four single-sequence runs bit
+    for bit (poses, map sizes, map points); (2) poses follow the synthetic trajectory; (3) gradients through
+    the recovered poses reach depth / intrinsics / first pose of EVERY sequence, are finite, and the batched
+    gradients equal the single-sequence ones."""
+    from gradslam_amd.synthetic import make_sequence
+
+    B, L, H, W = 4, 3, 968, 1296
+    c, dd, K, P = make_sequence(B, L, H, W, seed=11)
+    run = lambda sl: gs.slam.ICPSLAM(odom="gradicp", dsratio=4, numiters=6, device=DEV)(
+        gs.RGBDImages(*(x[sl].to(DEV) for x in (c, dd, K, P))))
+    with torch.no_grad():
+        pcs, poses = run(slice(0, B))
+        singles = [run(slice(b, b + 1)) for b in range(B)]
+    assert rel_err(poses.cpu(), P) < 3e-2
+    for b in range(B):
+        assert torch.equal(poses[b], singles[b][1][0])
+        assert pcs.points_list[b].shape == singles[b][0].points_list[0].shape
+        assert torch.equal(pcs.points_list[b], singles[b][0].points_list[0])
+    # gradient through the poses
+    def grads(sl):
+        leaves = [x[sl].to(DEV).clone().requires_grad_(True) for x in (dd, K, P)]
+        slam = gs.slam.ICPSLAM(odom="gradicp", dsratio=4, numiters=6, device=DEV)
+        _, rp = slam(gs.RGBDImages(c[sl].to(DEV), *leaves))
+        rp[:, -1, :3, 3].sum().backward()  # the last recovered camera position of every sequence
+        return [x.grad.cpu() for x in leaves]
+    gb = grads(slice(0, B))
+    assert all(torch.isfinite(g).all() for g in gb)
+    for b in range(B):
+        assert gb[0][b].abs().sum() > 0 and gb[2][b, 0].abs().sum() > 0
+    g1 = grads(slice(1, 2))
+    for name, a, s in zip(("depth", "intrinsics", "poses"), gb, g1):
+        print("c5 grads", name, "batched vs single rel err %.2e" % rel_err(a[1:2], s))
+        assert rel_err(a[1:2], s) < 1e-5, name
