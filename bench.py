@@ -130,7 +130,15 @@ def aux_pointfusion(gs, dev, raw, n_frames=30):
     err = float((poses.cpu() - P).abs().max())
     out = {"pointfusion_c3_forward_fps": round(n_frames / dt, 2), "frames": n_frames,
            "final_map_points": int(pcs.num_points_per_pointcloud.item()), "pose_max_abs_err_vs_gt": round(err, 5),
-           "note": "PointFusion(odom='icp') forward over a 640x480 synthetic sequence, not part of `value`"}
+           "note": "PointFusion(odom='icp') forward over a 640x480 synthetic sequence (arena-backed sequence driver: "
+                   "localise + map update = two C calls per frame, one host sync per sequence), not part of `value`"}
+    slam.streamed = False
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        slam(frames)
+        torch.cuda.synchronize()
+        out["pointfusion_c3_forward_fps_stepwise_api"] = round(n_frames / (time.perf_counter() - t0), 2)
     # forward + backward (BASELINE configs[2] asks for both), default odometry = gradicp, loss as in the golden vectors
     for rep in range(2):  # first pass warms the allocator
         leaves = [x.to(dev).clone().requires_grad_(True) for x in (c, d, K, P)]

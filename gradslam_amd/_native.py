@@ -31,6 +31,14 @@ SIGNATURES = {
     "gs_compact_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compact_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
     "gs_expand_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_sz, c_p]),
+    "gs_append_rows_ws_bytes": (c_sz, [c_i64]),
+    "gs_append_rows": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_fusion_merge_inplace_ws_bytes": (c_sz, [c_i, c_i]),
+    "gs_fusion_merge_inplace": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      c_sz, c_p]),
+    "gs_pointfusion_update_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "gs_pointfusion_update": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_p, c_p,
+                                    c_sz, c_p]),
     "gs_downsample_frame_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "gs_downsample_frame": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_build_icp_target_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
@@ -157,10 +165,12 @@ _ws_cache = {}
 
 def workspace(nbytes: int, device, tag: str = "default") -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream, tag).  Kernels of one call finish with it before
-    the next call on the same stream can start, so reuse is safe."""
+    the next call on the same stream can start, so reuse is safe.  Sizes are rounded up to a power of two:
+    a map that grows frame by frame then keeps its workspace ADDRESS for many frames, which is what lets
+    gs_slam_localize replay its captured graph (the address is part of the graph's key)."""
     key = (str(device), stream(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        buf = torch.empty(1 << max(int(nbytes) - 1, 255).bit_length(), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

@@ -141,6 +141,35 @@ __global__ void merge_k(const int *__restrict__ match_pix, const int32_t *__rest
 // adjoint of merge_k.  x' = (c x + a xf) / c2 (c2 != 0):
 //   x_bar = (c/c2) x'_bar ; xf_bar = (a/c2) x'_bar ; c_bar = c2_bar + sum (x - x').x'_bar / c2 ;
 //   a_bar = c2_bar + sum (xf - x').x'_bar / c2      (sums over points, normals, colours)
+// In-place form for an arena-backed map: same arithmetic on the rows that exist, padding untouched, and
+// nothing at all when there is no correspondence (fuse_with_map skips the merge then, fusionutils.py:654).
+__global__ void merge_inplace_k(const int *__restrict__ match_pix, const int32_t *__restrict__ counts,
+                                const int32_t *__restrict__ d_n_rows, int Nmax, int HW, const float *__restrict__ gv,
+                                const float *__restrict__ gn, const float *__restrict__ rgb, const float *__restrict__ alpha,
+                                float *p, float *nn, float *cl, float *cc) {
+    if (*d_n_rows == 0) return;
+    const int b = blockIdx.y;
+    const int cnt = min(counts[b], Nmax);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < cnt; n += gridDim.x * blockDim.x) {
+        const int64_t pt = (int64_t)b * Nmax + n;
+        const int m = match_pix[pt];
+        float a = 0.0f;
+        f3 fp{0, 0, 0}, fn{0, 0, 0}, fc{0, 0, 0};
+        if (m >= 0) {
+            const int64_t pix = (int64_t)b * HW + m;
+            a = alpha[pix]; fp = ld3(gv, pix); fn = ld3(gn, pix); fc = ld3(rgb, pix);
+        }
+        const float c = cc[pt];
+        const float c2 = c + a;
+        const float inv = 1.0f / (c2 == 0.0f ? 1.0f : c2);
+        const f3 x = ld3(p, pt), y = ld3(nn, pt), z = ld3(cl, pt);
+        st3(p, pt, f3{((c * x.x) + (a * fp.x)) * inv, ((c * x.y) + (a * fp.y)) * inv, ((c * x.z) + (a * fp.z)) * inv});
+        st3(nn, pt, f3{((c * y.x) + (a * fn.x)) * inv, ((c * y.y) + (a * fn.y)) * inv, ((c * y.z) + (a * fn.z)) * inv});
+        st3(cl, pt, f3{((c * z.x) + (a * fc.x)) * inv, ((c * z.y) + (a * fc.y)) * inv, ((c * z.z) + (a * fc.z)) * inv});
+        cc[pt] = c2;
+    }
+}
+
 __global__ void merge_bwd_k(const int *__restrict__ match_pix, const int32_t *__restrict__ counts, int Nmax, int HW,
                             const float *__restrict__ gv, const float *__restrict__ gn, const float *__restrict__ rgb,
                             const float *__restrict__ alpha, const float *__restrict__ ip, const float *__restrict__ inn,
@@ -298,6 +327,24 @@ int gs_fusion_merge(const int64_t *rows, const int32_t *d_n_rows, int64_t max_ro
                        gnormal, rgb, alpha, in_points, in_normals, in_colors, in_ccounts, out_points, out_normals,
                        out_colors, out_ccounts);
     GS_LAUNCH_CHECK("gs_fusion_merge");
+    return GS_OK;
+}
+
+size_t gs_fusion_merge_inplace_ws_bytes(int B, int Nmax) { return gs_fusion_merge_ws_bytes(B, Nmax); }
+
+int gs_fusion_merge_inplace(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
+                            const float *gnormal, const float *rgb, const float *alpha, int B, int H, int W, int Nmax,
+                            const int32_t *counts, float *points, float *normals, float *colors, float *ccounts, void *ws,
+                            size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(rows && d_n_rows && gvertex && gnormal && rgb && alpha && counts && points && normals && colors && ccounts,
+               "gs_fusion_merge_inplace: NULL argument");
+    GS_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && Nmax > 0 && max_rows >= 0, "gs_fusion_merge_inplace: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_match(rows, d_n_rows, max_rows, B, H, W, Nmax, ws, ws_bytes, st, "gs_fusion_merge_inplace");
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(merge_inplace_k, dim3(grid1d(Nmax), B), dim3(256), 0, st, (const int *)ws, counts, d_n_rows, Nmax, H * W,
+                       gvertex, gnormal, rgb, alpha, points, normals, colors, ccounts);
+    GS_LAUNCH_CHECK("gs_fusion_merge_inplace");
     return GS_OK;
 }
 

@@ -397,6 +397,39 @@ struct MultiWriter {
     }
 };
 
+// MultiWriter that appends: selected rows go behind the *base rows a destination already holds (device-side
+// count), rows that would not fit into `cap` are dropped (the caller sizes cap so that this never happens and
+// checks the overflow flag)
+struct AppendWriter {
+    const uint32_t *src[4];
+    uint32_t *out[4];
+    int words[4];
+    int n_arrays;
+    const int32_t *base;
+    int cap;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int64_t at = (int64_t)(*base) + pos;
+        if (at >= cap) return;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a >= n_arrays) break;
+            const int w = words[a];
+            for (int k = 0; k < w; ++k) out[a][at * w + k] = src[a][i * w + k];
+        }
+    }
+};
+
+__global__ void append_count_k(int32_t *__restrict__ count, const int *__restrict__ total, int cap,
+                               int32_t *__restrict__ appended, int32_t *__restrict__ overflow) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t want = (int64_t)*count + *total;
+        const int now = (int)(want > cap ? cap : want);
+        if (appended) *appended = now - *count;
+        if (overflow && want > cap) *overflow = 1;
+        *count = now;
+    }
+}
+
 // adjoint of MultiWriter: row i of every output = the compacted row it went to, or zero
 struct ExpandWriter {
     const uint32_t *g[4];
@@ -554,6 +587,36 @@ int gs_expand_multi(int n_arrays, const float *const *h_grad, const int *h_row_f
     }
     MaskPred pred{mask};
     return compact_launch(n_rows, pred, wr, (int *)nullptr, ws, (hipStream_t)stream, "gs_expand_multi");
+}
+
+size_t gs_append_rows_ws_bytes(int64_t n_rows) { return compact_ws_bytes(n_rows) + 256; }
+
+int gs_append_rows(int n_arrays, const float *const *h_src, const int *h_row_floats, float *const *h_dst, const uint8_t *mask,
+                   int64_t n_rows, int32_t *d_count, int cap, int32_t *d_appended, int32_t *d_overflow, void *ws,
+                   size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(n_arrays >= 1 && n_arrays <= 4 && h_src && h_row_floats && h_dst && mask && d_count && n_rows >= 0 && cap >= 0,
+               "gs_append_rows: bad arguments (1..4 arrays)");
+    if (ws_bytes < gs_append_rows_ws_bytes(n_rows) || !ws) {
+        set_error("gs_append_rows: workspace too small (%zu < %zu)", ws_bytes, gs_append_rows_ws_bytes(n_rows));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    AppendWriter wr;
+    wr.n_arrays = n_arrays;
+    wr.base = d_count;
+    wr.cap = cap;
+    for (int a = 0; a < 4; ++a) {
+        wr.src[a] = a < n_arrays ? (const uint32_t *)h_src[a] : nullptr;
+        wr.out[a] = a < n_arrays ? (uint32_t *)h_dst[a] : nullptr;
+        wr.words[a] = a < n_arrays ? h_row_floats[a] : 0;
+        GS_REQUIRE(a >= n_arrays || (h_src[a] && h_dst[a] && h_row_floats[a] > 0), "gs_append_rows: NULL array %d", a);
+    }
+    int *total = (int *)((char *)ws + compact_ws_bytes(n_rows));
+    MaskPred pred{mask};
+    const int rc = compact_launch(n_rows, pred, wr, total, ws, (hipStream_t)stream, "gs_append_rows");
+    if (rc) return rc;
+    hipLaunchKernelGGL(append_count_k, dim3(1), dim3(64), 0, (hipStream_t)stream, d_count, total, cap, d_appended, d_overflow);
+    GS_LAUNCH_CHECK("gs_append_rows/count");
+    return GS_OK;
 }
 
 size_t gs_downsample_frame_ws_bytes(int H, int W, int ds) {

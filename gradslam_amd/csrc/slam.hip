@@ -118,6 +118,50 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     return off;
 }
 
+// ------------------------------------------------------------------ PointFusion map update on an arena
+struct FuseWs {
+    float *V, *N, *gV, *gN, *alpha;  // (B,H,W,3) x4, (B,H,W)
+    int64_t *rows;                   // (B*Nmax, 4) active rows
+    int64_t *urows;                  // (B*H*W, 4) unique rows
+    uint8_t *keep, *mask;            // (B*Nmax), (B*H*W)
+    int32_t *nrows, *ucnt, *appended, *overflow;  // (1),(1),(B),(1)
+    float *max_dot;                  // (1)
+    void *sub;
+    size_t sub_bytes;
+};
+static size_t fuse_layout(int B, int H, int W, int Nmax, void *ws, FuseWs *out) {
+    const size_t npix = (size_t)B * H * W, npt = (size_t)B * Nmax;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t oV = take(npix * 12), oN = take(npix * 12), ogV = take(npix * 12), ogN = take(npix * 12), oA = take(npix * 4);
+    const size_t oR = take(npt * 32), oU = take(npix * 32), oK = take(npt), oM = take(npix);
+    const size_t oC = take(256 + (size_t)B * 4);
+    size_t sub = gs_project_active_ws_bytes(B, Nmax);
+    sub = std::max(sub, gs_fusion_unique_ws_bytes(B, H, W));
+    sub = std::max(sub, gs_fusion_merge_inplace_ws_bytes(B, Nmax));
+    sub = std::max(sub, gs_append_rows_ws_bytes((int64_t)H * W));
+    const size_t oS = take(sub);
+    if (ws && out) {
+        char *p = (char *)ws;
+        out->V = (float *)(p + oV); out->N = (float *)(p + oN); out->gV = (float *)(p + ogV); out->gN = (float *)(p + ogN);
+        out->alpha = (float *)(p + oA); out->rows = (int64_t *)(p + oR); out->urows = (int64_t *)(p + oU);
+        out->keep = (uint8_t *)(p + oK); out->mask = (uint8_t *)(p + oM);
+        int32_t *c = (int32_t *)(p + oC);
+        out->nrows = c; out->ucnt = c + 1; out->overflow = c + 2; out->max_dot = (float *)(c + 3); out->appended = c + 64;
+        out->sub = p + oS; out->sub_bytes = sub;
+    }
+    return off;
+}
+
+__global__ void fuse_stats_k(const int32_t *__restrict__ nrows, const int32_t *__restrict__ ucnt, const int32_t *__restrict__ overflow,
+                             const float *__restrict__ max_dot, const int32_t *__restrict__ appended, int B,
+                             int32_t *__restrict__ stats) {
+    if (threadIdx.x == 0) {
+        stats[0] = *nrows; stats[1] = *ucnt; stats[2] = *overflow; stats[3] = __float_as_int(*max_dot);
+    }
+    if ((int)threadIdx.x < B) stats[4 + threadIdx.x] = appended[threadIdx.x];
+}
+
 // ------------------------------------------------------------------ differentiable localisation
 // Tape of one gs_slam_localize_taped call: what the reverse pass cannot cheaply recompute.
 struct LocTape {
@@ -317,6 +361,59 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     }
     if (!launched && (rc = enqueue_loops(stream))) return rc;
     return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);
+}
+
+size_t gs_pointfusion_update_ws_bytes(int B, int H, int W, int Nmax) {
+    if (B <= 0 || H <= 0 || W <= 0 || Nmax <= 0) return 0;
+    return fuse_layout(B, H, W, Nmax, nullptr, nullptr);
+}
+
+int gs_pointfusion_update(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H, int W,
+                          float *map_points, float *map_normals, float *map_colors, float *map_ccounts, int32_t *map_counts,
+                          int Nmax, float dist_th, float dot_th, float sigma, int32_t *stats, void *ws, size_t ws_bytes,
+                          gs_stream_t stream) {
+    const char *name = "gs_pointfusion_update";
+    GS_REQUIRE(depth && rgb && intrinsics && poses && map_points && map_normals && map_colors && map_ccounts && map_counts,
+               "%s: NULL argument", name);
+    GS_REQUIRE(B > 0 && B <= 60 && H >= 2 && W >= 2 && Nmax > 0, "%s: bad shape", name);
+    if (!ws || ws_bytes < gs_pointfusion_update_ws_bytes(B, H, W, Nmax)) {
+        set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, gs_pointfusion_update_ws_bytes(B, H, W, Nmax));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    FuseWs w;
+    fuse_layout(B, H, W, Nmax, ws, &w);
+    const int64_t npix = (int64_t)B * H * W, npt = (int64_t)B * Nmax;
+    int rc;
+    GS_HIP(hipMemsetAsync(w.nrows, 0, 256 + (size_t)B * 4, st), name);  // counters, flags, max_dot
+    // live frame under its final pose; sample confidence from the local vertex map (fusionutils.py:650-652)
+    if ((rc = gs_vertex_normal_maps(depth, intrinsics, poses, B, 1, H, W, w.V, w.N, w.gV, w.gN, stream))) return rc;
+    if ((rc = gs_get_alpha(w.V, npix, sigma, 1e-7f, w.alpha, stream))) return rc;
+    // find_correspondences (fusionutils.py:549-577): active -> similar -> best unique per pixel
+    if ((rc = gs_project_active(map_points, map_counts, B, Nmax, poses, intrinsics, H, W, 0, w.rows, w.nrows, w.sub, w.sub_bytes,
+                                stream))) return rc;
+    if ((rc = gs_fusion_similar(w.rows, w.nrows, npt, w.gV, w.gN, H, W, map_points, map_normals, Nmax, dist_th, dot_th, w.keep,
+                                w.max_dot, stream))) return rc;
+    if ((rc = gs_fusion_unique(w.rows, w.keep, w.nrows, npt, w.gV, B, H, W, map_points, map_ccounts, Nmax, w.urows, w.ucnt, w.sub,
+                               w.sub_bytes, stream))) return rc;
+    // fuse_with_map (fusionutils.py:654-720): merge in place, then append the unmatched valid pixels
+    if ((rc = gs_fusion_merge_inplace(w.urows, w.ucnt, npix, w.gV, w.gN, rgb, w.alpha, B, H, W, Nmax, map_counts, map_points,
+                                      map_normals, map_colors, map_ccounts, w.sub, w.sub_bytes, stream))) return rc;
+    if ((rc = gs_fusion_new_mask(depth, w.urows, w.ucnt, npix, B, H, W, w.mask, stream))) return rc;
+    const int64_t HW = (int64_t)H * W;
+    for (int b = 0; b < B; ++b) {
+        const float *src[4] = {w.gV + b * HW * 3, w.gN + b * HW * 3, rgb + b * HW * 3, w.alpha + b * HW};
+        float *dst[4] = {map_points + (size_t)b * Nmax * 3, map_normals + (size_t)b * Nmax * 3, map_colors + (size_t)b * Nmax * 3,
+                         map_ccounts + (size_t)b * Nmax};
+        const int widths[4] = {3, 3, 3, 1};
+        if ((rc = gs_append_rows(4, src, widths, dst, w.mask + b * HW, HW, map_counts + b, Nmax, w.appended + b, w.overflow, w.sub,
+                                 w.sub_bytes, stream))) return rc;
+    }
+    if (stats) {
+        hipLaunchKernelGGL(fuse_stats_k, dim3(1), dim3(64), 0, st, w.nrows, w.ucnt, w.overflow, w.max_dot, w.appended, B, stats);
+        GS_LAUNCH_CHECK(name);
+    }
+    return GS_OK;
 }
 
 size_t gs_slam_localize_tape_bytes(int B, int H, int W, int ds, int Nmax, int numiters, int use_grad_lm) {

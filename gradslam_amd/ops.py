@@ -543,6 +543,26 @@ def slam_localize_autograd(gV, depth, K, prev_poses, map_points, map_normals, ma
                              grad_params)
 
 
+def pointfusion_update_raw(depth, rgb, K, poses, map_points, map_normals, map_colors, map_ccounts, map_counts_i32, dist_th,
+                           dot_th, sigma, stats=None):
+    """One fused, sync-free PointFusion map update on arena arrays (reference slam/fusionutils.py:761-789 with
+    inplace=True).  depth (B,H,W[,1]), rgb (B,H,W,3), K / poses (B,[1,]4,4); map_* (B,Nmax,C) float32 contiguous,
+    rows beyond map_counts zero; the caller guarantees counts + H*W <= Nmax.  Everything is updated in place,
+    including map_counts_i32 (B,) int32 on the device; `stats` (4+B,) int32 receives the step's counters."""
+    require_hip(depth, rgb, K, poses, map_points, map_normals, map_colors, map_ccounts, map_counts_i32, op="pointfusion_update")
+    for name, x in (("map_points", map_points), ("map_normals", map_normals), ("map_colors", map_colors),
+                    ("map_ccounts", map_ccounts), ("depth", depth), ("rgb", rgb)):
+        if not (x.is_contiguous() and x.dtype == torch.float32):
+            raise ValueError("pointfusion_update: {} must be contiguous float32 (it is updated / read in place)".format(name))
+    B, H, W = depth.shape[:3]
+    Nmax = map_points.shape[1]
+    K, poses = _f32c(K), _f32c(poses)
+    ws = workspace(ws_bytes("gs_pointfusion_update_ws_bytes", B, H, W, Nmax), depth.device, "fusion_step")
+    call("gs_pointfusion_update", ptr(depth), ptr(rgb), ptr(K), ptr(poses), B, H, W, ptr(map_points), ptr(map_normals),
+         ptr(map_colors), ptr(map_ccounts), ptr(map_counts_i32), Nmax, float(dist_th), float(dot_th), float(sigma), ptr(stats),
+         ptr(ws), ws.numel(), stream())
+
+
 # ---------------------------------------------------------------------------------------------- C / U / F / A
 def fusion_similar_raw(rows, n_rows_dev, max_rows, gV, gN, map_points, map_normals, dist_th, dot_th):
     """-> keep (max_rows,) uint8, max_dot (1,) float32 device."""

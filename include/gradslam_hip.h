@@ -80,6 +80,14 @@ int gs_compact_rows(const float *src, const uint8_t *mask, int64_t n_rows, int r
 int gs_compact_multi(int n_arrays, const float *const *h_src, const int *h_row_floats,
                      float *const *h_out, const uint8_t *mask, int64_t n_rows, int32_t *out_count,
                      void *ws, size_t ws_bytes, gs_stream_t stream);
+/* Append form: the selected rows of every h_src[a] go behind the *d_count rows h_dst[a] (capacity `cap` rows)
+ * already holds; *d_count advances on the device (no host round trip), d_appended / d_overflow (optional)
+ * receive the number of rows appended and a flag set when rows had to be dropped for lack of capacity.
+ * This is Pointclouds.append_points (structures/pointclouds.py:1203-1235) for an arena-backed map. */
+size_t gs_append_rows_ws_bytes(int64_t n_rows);
+int gs_append_rows(int n_arrays, const float *const *h_src, const int *h_row_floats, float *const *h_dst,
+                   const uint8_t *mask, int64_t n_rows, int32_t *d_count, int cap, int32_t *d_appended,
+                   int32_t *d_overflow, void *ws, size_t ws_bytes, gs_stream_t stream);
 /* Adjoint of gs_compact_multi (what autograd does for x[mask] in the reference): h_out[a] (n_rows, w_a)
  * receives the compacted adjoint row of every selected row and zeros everywhere else. */
 int gs_expand_multi(int n_arrays, const float *const *h_grad, const int *h_row_floats,
@@ -254,6 +262,22 @@ int gs_icp_point_to_plane_backward(const float *src, const int32_t *d_ns, int ma
                                    float *grad_normals, float *grad_init_T, void *ws, size_t ws_bytes,
                                    gs_stream_t stream);
 
+/* ---------------------------------------------------------------- whole PointFusion map update
+ * update_map_fusion(pointclouds, live_frame, dist_th, dot_th, sigma, inplace=True)
+ * (slam/fusionutils.py:761-789 = find_correspondences :549-577 + fuse_with_map :580-722) as ONE call with no
+ * host synchronisation, on a map kept in caller-owned arena arrays: map_* are (B, Nmax, C) with the rows
+ * n >= map_counts[b] zero; matched points are merged in place, the unmatched valid pixels of the live frame are
+ * appended behind them in (h, w) order and map_counts advances ON THE DEVICE.  Nmax is both the row stride
+ * and the capacity: the caller guarantees map_counts[b] + H*W <= Nmax (stats[2] flags a violation; rows that
+ * do not fit are dropped).  depth (B,H,W), rgb (B,H,W,3), intrinsics / poses (B,16; poses = the live frame's
+ * pose).  stats (optional, 4 + B int32): active rows, unique correspondences, overflow flag, max normal
+ * dot product (float bits), appended rows per batch element -- what the reference's warnings are raised from. */
+size_t gs_pointfusion_update_ws_bytes(int B, int H, int W, int Nmax);
+int gs_pointfusion_update(const float *depth, const float *rgb, const float *intrinsics, const float *poses,
+                          int B, int H, int W, float *map_points, float *map_normals, float *map_colors,
+                          float *map_ccounts, int32_t *map_counts, int Nmax, float dist_th, float dot_th,
+                          float sigma, int32_t *stats, void *ws, size_t ws_bytes, gs_stream_t stream);
+
 /* ---------------------------------------------------------------- differentiable localisation step
  * gs_slam_localize with autograd (the same stages; gvertex = the live frame's global vertex map under the
  * PREVIOUS pose is an input here, so that its own adjoint chains into gs_vertex_normal_maps_backward).
@@ -355,6 +379,16 @@ int gs_fusion_merge_backward(const int64_t *rows, const int32_t *d_n_rows, int64
                              float *g_in_colors, float *g_in_ccounts, float *g_gvertex,
                              float *g_gnormal, float *g_rgb, float *g_alpha, void *ws,
                              size_t ws_bytes, gs_stream_t stream);
+
+/* In-place form of gs_fusion_merge for an arena-backed map: the rows that exist (n < counts[b]) are merged
+ * where they are, padding is not touched, and nothing happens at all when *d_n_rows == 0 (fuse_with_map
+ * skips the merge when there is no correspondence, slam/fusionutils.py:654). */
+size_t gs_fusion_merge_inplace_ws_bytes(int B, int Nmax);
+int gs_fusion_merge_inplace(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows,
+                            const float *gvertex, const float *gnormal, const float *rgb,
+                            const float *alpha, int B, int H, int W, int Nmax, const int32_t *counts,
+                            float *points, float *normals, float *colors, float *ccounts, void *ws,
+                            size_t ws_bytes, gs_stream_t stream);
 
 /* ---------------------------------------------------------------- A: new-point mask
  * fuse_with_map's append mask (slam/fusionutils.py:702-707): mask = valid_depth && pixel not in

@@ -670,3 +670,28 @@ def test_config5_shape_batch_independence_and_pose_gradients(gs):
     for name, a, s in zip(("depth", "intrinsics", "poses"), gb, g1):
         print("c5 grads", name, "batched vs single rel err %.2e" % rel_err(a[1:2], s))
         assert rel_err(a[1:2], s) < 1e-5, name
+
+
+@pytest.mark.parametrize("odom,B", [("icp", 1), ("gradicp", 2), ("gt", 2)])
+def test_streamed_arena_forward_equals_stepwise(gs, odom, B):
+    """PointFusion.forward on the arena-backed driver (two C calls per frame, device-resident counts, one host
+    sync per sequence) returns bit for bit what the step-by-step path returns, including when the arena has to
+    grow (8 frames at 160x120 start from a 2*H*W-row arena)."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(B, 8, 120, 160, seed=21)
+    frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
+    out = {}
+    for streamed in (True, False):
+        slam = gs.slam.PointFusion(odom=odom, dsratio=2, numiters=6, device=DEV)
+        slam.streamed = streamed
+        with torch.no_grad():
+            out[streamed] = slam(frames)
+    (pa, qa), (pb, qb) = out[True], out[False]
+    assert torch.equal(qa, qb)
+    assert pa.num_points_per_pointcloud.tolist() == pb.num_points_per_pointcloud.tolist()
+    for attr in ("points_list", "normals_list", "colors_list", "features_list"):
+        for b in range(B):
+            assert torch.equal(getattr(pa, attr)[b], getattr(pb, attr)[b]), (attr, b)
+    # padded views keep the zero-padding contract
+    assert torch.equal(pa.points_padded, pb.points_padded)
