@@ -27,6 +27,7 @@ SIGNATURES = {
                                              c_p, c_sz, c_p]),
     "gs_get_alpha": (c_i, [c_p, c_i64, c_f, c_f, c_p, c_p]),
     "gs_get_alpha_backward": (c_i, [c_p, c_i64, c_f, c_f, c_p, c_p, c_p]),
+    "gs_frames_from_raw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p]),
     "gs_compact_ws_bytes": (c_sz, [c_i64]),
     "gs_compact_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compact_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),

@@ -397,6 +397,44 @@ struct MultiWriter {
     }
 };
 
+// Raw sensor frames -> the float tensors of RGBDImages, on the device (reference datasets/tum.py:346,
+// :455-499): depth = uint16 / scaling_factor with nearest-neighbour resize, colour = uint8 (optionally / 255)
+// with bilinear resize (pixel centres at +0.5, edges clamped).  fp64 inside, rounded once, like the
+// reference's float64 numpy arithmetic followed by .float().  Same-size frames are exact copies.
+__global__ void frames_from_raw_k(const uint16_t *__restrict__ depth_raw, const uint8_t *__restrict__ rgb_raw, int Hs, int Ws,
+                                  int Hd, int Wd, double depth_scale, int normalise, float *__restrict__ depth,
+                                  float *__restrict__ rgb) {
+    const int b = blockIdx.y;
+    const int64_t npix = (int64_t)Hd * Wd;
+    const double ry = (double)Hs / Hd, rx = (double)Ws / Wd;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / Wd), x = (int)(p - (int64_t)y * Wd);
+        if (depth_raw) {
+            const int sy = min((int)floor(y * ry), Hs - 1), sx = min((int)floor(x * rx), Ws - 1);
+            depth[(int64_t)b * npix + p] = (float)((double)depth_raw[((int64_t)b * Hs + sy) * Ws + sx] / depth_scale);
+        }
+        if (rgb_raw) {
+            double fy = (y + 0.5) * ry - 0.5, fx = (x + 0.5) * rx - 0.5;
+            int y0 = (int)floor(fy), x0 = (int)floor(fx);
+            fy -= y0; fx -= x0;
+            if (y0 < 0) { y0 = 0; fy = 0.0; }
+            if (x0 < 0) { x0 = 0; fx = 0.0; }
+            if (y0 >= Hs - 1) { y0 = Hs - 1; fy = 0.0; }
+            if (x0 >= Ws - 1) { x0 = Ws - 1; fx = 0.0; }
+            const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+            const uint8_t *img = rgb_raw + (int64_t)b * Hs * Ws * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double v00 = img[((int64_t)y0 * Ws + x0) * 3 + c], v01 = img[((int64_t)y0 * Ws + x1) * 3 + c];
+                const double v10 = img[((int64_t)y1 * Ws + x0) * 3 + c], v11 = img[((int64_t)y1 * Ws + x1) * 3 + c];
+                double v = (v00 * (1.0 - fx) + v01 * fx) * (1.0 - fy) + (v10 * (1.0 - fx) + v11 * fx) * fy;
+                if (normalise) v /= 255.0;
+                rgb[((int64_t)b * npix + p) * 3 + c] = (float)v;
+            }
+        }
+    }
+}
+
 // MultiWriter that appends: selected rows go behind the *base rows a destination already holds (device-side
 // count), rows that would not fit into `cap` are dropped (the caller sizes cap so that this never happens and
 // checks the overflow flag)
@@ -587,6 +625,17 @@ int gs_expand_multi(int n_arrays, const float *const *h_grad, const int *h_row_f
     }
     MaskPred pred{mask};
     return compact_launch(n_rows, pred, wr, (int *)nullptr, ws, (hipStream_t)stream, "gs_expand_multi");
+}
+
+int gs_frames_from_raw(const uint16_t *depth_raw, const uint8_t *rgb_raw, int B, int Hs, int Ws, int Hd, int Wd,
+                       float depth_scale, int normalise_color, float *depth, float *rgb, gs_stream_t stream) {
+    GS_REQUIRE(B > 0 && B <= 65535 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "gs_frames_from_raw: bad shape");
+    GS_REQUIRE((!depth_raw || depth) && (!rgb_raw || rgb) && (depth_raw || rgb_raw), "gs_frames_from_raw: NULL output for a given input");
+    GS_REQUIRE(!depth_raw || depth_scale > 0.0f, "gs_frames_from_raw: depth_scale must be positive");
+    hipLaunchKernelGGL(frames_from_raw_k, dim3(min(cdiv((int64_t)Hd * Wd, 256), 2048), B), dim3(256), 0, (hipStream_t)stream,
+                       depth_raw, rgb_raw, Hs, Ws, Hd, Wd, (double)depth_scale, normalise_color, depth, rgb);
+    GS_LAUNCH_CHECK("gs_frames_from_raw");
+    return GS_OK;
 }
 
 size_t gs_append_rows_ws_bytes(int64_t n_rows) { return compact_ws_bytes(n_rows) + 256; }

@@ -214,6 +214,24 @@ def mask_select(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return compact_rows(x, mask)
 
 
+def frames_from_raw(depth_u16, rgb_u8, height: int, width: int, depth_scale: float, normalize_color: bool):
+    """Raw sensor frames on the device -> float32 (depth (B,H,W,1), rgb (B,H,W,3)); either input may be None.
+    depth_u16 (B,Hs,Ws) int16/uint16 storage, rgb_u8 (B,Hs,Ws,3) uint8 (reference datasets/tum.py:455-499)."""
+    ref = depth_u16 if depth_u16 is not None else rgb_u8
+    require_hip(*(x for x in (depth_u16, rgb_u8) if x is not None), op="frames_from_raw")
+    B, Hs, Ws = ref.shape[:3]
+    dev = ref.device
+    if depth_u16 is not None and not (depth_u16.is_contiguous() and depth_u16.element_size() == 2):
+        raise ValueError("frames_from_raw: depth must be a contiguous 16-bit integer tensor")
+    if rgb_u8 is not None and not (rgb_u8.is_contiguous() and rgb_u8.dtype == torch.uint8 and rgb_u8.shape[-1] == 3):
+        raise ValueError("frames_from_raw: rgb must be a contiguous uint8 (B,H,W,3) tensor")
+    depth = torch.empty((B, height, width, 1), dtype=torch.float32, device=dev) if depth_u16 is not None else None
+    rgb = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev) if rgb_u8 is not None else None
+    call("gs_frames_from_raw", ptr(depth_u16), ptr(rgb_u8), B, Hs, Ws, int(height), int(width), float(depth_scale),
+         1 if normalize_color else 0, ptr(depth), ptr(rgb), stream())
+    return depth, rgb
+
+
 # ---------------------------------------------------------------------------------------------- D
 def downsample_frame_raw(depth, gV, gN, rgb, ds: int):
     """One-frame maps (B,1,H,W,C) -> padded (B,cap,3) x3 + counts (B,) int32 device

@@ -66,6 +66,15 @@ int gs_get_alpha(const float *points, int64_t n, float sigma, float eps, float *
 int gs_get_alpha_backward(const float *points, int64_t n, float sigma, float eps,
                           const float *g_alpha, float *g_points, gs_stream_t stream);
 
+/* ---------------------------------------------------------------- dataset front-end: raw frames -> float
+ * What the reference's dataset loaders do per frame on the host (datasets/tum.py:346, :455-499; icl.py:387;
+ * scannet.py:189), done on the device from the raw integer frames so that 5 instead of 16 bytes per pixel
+ * cross PCIe: depth (B,Hd,Wd) = uint16 (B,Hs,Ws) / depth_scale, nearest-neighbour resize; rgb (B,Hd,Wd,3) =
+ * uint8 (B,Hs,Ws,3), bilinear resize (pixel centres at +0.5), optionally / 255.  Either input may be NULL. */
+int gs_frames_from_raw(const uint16_t *depth_raw, const uint8_t *rgb_raw, int B, int Hs, int Ws, int Hd,
+                       int Wd, float depth_scale, int normalise_color, float *depth, float *rgb,
+                       gs_stream_t stream);
+
 /* ---------------------------------------------------------------- generic stable compaction
  * out = rows of `src` (n_rows x row_floats fp32) whose mask byte is non-zero, order preserved;
  * *out_count = number kept.  Replaces the boolean-mask indexing x[mask] the reference uses at
