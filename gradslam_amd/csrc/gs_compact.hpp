@@ -2,9 +2,12 @@
 //
 // The reference selects rows with boolean-mask indexing (x[mask]) whose output order is the input
 // order; map-point order and (h,w) row-major append order are user-visible, so the compaction
-// must be stable.  Three launches: per-block counts -> single-block scan -> ordered write.  The
+// must be stable.  Launches: per-block counts -> [single-block scan] -> ordered write.  The
 // predicate is re-evaluated in the write pass (cheap, inputs are L2/MALL resident) instead of
 // materialising flags.  No inter-workgroup hand-off inside a launch, so no coherence protocol.
+// Up to kSelfScanBlocks blocks the scan is not a launch of its own: a dependent launch costs ~4.5 us of
+// stream time on this part however small, whereas every write block adding up the counts of the blocks in
+// front of it (<= 1024 L2-resident ints, one coalesced read + a block reduction) costs well under 1 us.
 #pragma once
 
 #include <type_traits>
@@ -68,10 +71,49 @@ static __global__ __launch_bounds__(1024) void compact_scan_k(const int *__restr
     if (threadIdx.x == 0 && out_total) out_total[0] = carry;
 }
 
-template <class Pred, class Writer>
+constexpr int kSelfScanBlocks = 1024;
+
+// sum of counts[0 .. blockIdx.x) by the whole block; the last block also publishes the grand total
+__device__ __forceinline__ int self_scan_offset(const int *__restrict__ block_counts, int *__restrict__ out_total) {
+    __shared__ int red[kCT / 64];
+    __shared__ int result;
+    int mine = 0, all = 0;
+    const bool last = blockIdx.x == gridDim.x - 1;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += kCT) {
+        const int c = (j < (int)blockIdx.x || last) ? block_counts[j] : 0;
+        if (j < (int)blockIdx.x) mine += c;
+        all += c;
+    }
+    mine = wave_sum_i(mine);
+    all = wave_sum_i(all);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < kCT / 64; ++w) s += red[w];
+        result = s;
+    }
+    __syncthreads();
+    const int off = result;
+    if (last && out_total) {  // block-uniform branch
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = all;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int w = 0; w < kCT / 64; ++w) s += red[w];
+            out_total[0] = s;
+        }
+    }
+    return off;
+}
+
+template <class Pred, class Writer, bool SelfScan = false>
 __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Writer writer,
-                                                       const int *__restrict__ block_offsets) {
+                                                       const int *__restrict__ block_offsets /* SelfScan: block COUNTS */,
+                                                       int *__restrict__ out_total = nullptr) {
     __shared__ int sm[kCT / 64 + 1];
+    const int block_base = SelfScan ? self_scan_offset(block_offsets, out_total) : block_offsets[blockIdx.x];
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     bool f[kCI];
     int c = 0;
@@ -82,7 +124,7 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
         c += f[k] ? 1 : 0;
     }
     int total;
-    int pos = block_offsets[blockIdx.x] + block_excl_scan<kCT>(c, sm, &total);
+    int pos = block_base + block_excl_scan<kCT>(c, sm, &total);
 #pragma unroll
     for (int k = 0; k < kCI; ++k) {
         if (f[k]) {
@@ -103,9 +145,15 @@ static inline int compact_launch(int64_t n, Pred pred, Writer writer, int *d_out
     int *offsets = counts + nb;
     hipLaunchKernelGGL((compact_count_k<Pred>), dim3(nb), dim3(kCT), 0, st, n, pred, counts);
     GS_LAUNCH_CHECK(name);
+    if (nb <= kSelfScanBlocks) {
+        hipLaunchKernelGGL((compact_write_k<Pred, Writer, true>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, counts, d_out_count);
+        GS_LAUNCH_CHECK(name);
+        return GS_OK;
+    }
     hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, st, counts, nb, offsets, d_out_count);
     GS_LAUNCH_CHECK(name);
-    hipLaunchKernelGGL((compact_write_k<Pred, Writer>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, offsets);
+    hipLaunchKernelGGL((compact_write_k<Pred, Writer, false>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, offsets,
+                       (int *)nullptr);
     GS_LAUNCH_CHECK(name);
     return GS_OK;
 }

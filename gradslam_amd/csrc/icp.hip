@@ -442,80 +442,6 @@ struct LoopBufs {
     __host__ __device__ unsigned long long *N(int s) const { return best + s * best_stride; }
 };
 
-// Association launch of the loops: in = (first ? user source : pts[p_cur]) transformed by S->dT,
-// out = pts[out_slot], NN -> best[out_slot]  (out_slot < 0: the other one of the two ping-pong slots).  Seed: the current cloud's NN of the same source index
-// when there is one, else the sampled seed pass.
-__global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S, int first, int out_slot,
-                                                      const float *__restrict__ user_src, LoopBufs B,
-                                                      const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
-                                                      const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
-                                                      const float *__restrict__ nrm, float thresh,
-                                                      float *__restrict__ partials /* gridDim.x x NACC */,
-                                                      gs_icp_hints hints) {
-    __shared__ KnnShared sh;
-    const int ns = *d_ns, nt = *d_nt;
-    const int tile0 = blockIdx.x * 64;
-    if (tile0 >= ns) {  // empty tile: its partial row must still be defined
-        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
-        return;
-    }
-    const int p_cur = S->p_cur, b_cur = S->b_cur;
-    const float *in = first ? user_src : B.P(p_cur);
-    float *out = B.P(out_slot >= 0 ? out_slot : 1 - p_cur);
-    unsigned long long *best = B.N(out_slot >= 0 ? out_slot : 1 - b_cur);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = tile0 + lane;
-    const bool ok = i < ns;
-    f3 s{0.0f, 0.0f, 0.0f};
-    if (ok) {
-        s = xform(S->dT, ld3(in, i));
-        if (wave == 0) st3(out, i, s);
-    }
-    if (nt <= 0) {
-        if (ok && wave == 0) best[i] = KEY_NONE;
-        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
-        return;
-    }
-    int sj = -1;
-    if (!first) {
-        sj = 0;
-        if (ok) {
-            const unsigned long long k = B.N(b_cur)[i];
-            sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
-        }
-    }
-    const bool window_seed = first && hints.scan_points && hints.src_pix && hints.pix_start && hints.grid_w > 0;
-    if (window_seed) sj = -2;  // seeded by knn_window_seed below (block-uniform decision)
-    const float *scan = hints.scan_points ? hints.scan_points : tgt;
-    const int32_t *scan_orig = hints.scan_points ? hints.scan_orig : nullptr;
-    if (window_seed) knn_window_seed(sh, s, ok, i, hints, nt);
-    const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, scan, scan_orig, boxes, nt);
-    // linearise this tile straight away (J fused into K's epilogue): 29 sums over the tile's 64 points,
-    // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
-    if (wave == 0) {
-        if (ok) best[i] = key;
-        float acc[NACC];
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-        const Row r = make_row_from(s, ok, key, tgt, nrm, thresh);
-        if (r.valid) accumulate_row(r, acc);
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) sh.rows[k][lane] = acc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC * 16) {
-        const int k = threadIdx.x >> 4, p4 = (threadIdx.x & 15) * 4;
-        sh.part[k][threadIdx.x & 15] = ((sh.rows[k][p4] + sh.rows[k][p4 + 1]) + sh.rows[k][p4 + 2]) + sh.rows[k][p4 + 3];
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        float v = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v += sh.part[threadIdx.x][q];
-        partials[blockIdx.x * NACC + threadIdx.x] = v;
-    }
-}
-
 // Stand-alone pruned search (gs_knn1): no transform, sampled seed pass.
 __global__ __launch_bounds__(KNN_BT) void knn1_box_k(const float *__restrict__ src, const int32_t *__restrict__ d_ns,
                                                      const float *__restrict__ tgt, const float *__restrict__ boxes,
@@ -591,8 +517,16 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
     __shared__ float stage[32][33];
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // blockDim.x == 1024 -> g in [0, 32)
     float v = 0.0f;
-    if (k < NACC)
-        for (int b = g; b < nblocks; b += 32) v += partials[b * NACC + k];
+    if (k < NACC) {
+        // four independent loads in flight per round (the rows are L2-resident; latency, not bandwidth, is the cost)
+        int b = g;
+        for (; b + 96 < nblocks; b += 128) {
+            const float a0 = partials[b * NACC + k], a1 = partials[(b + 32) * NACC + k];
+            const float a2 = partials[(b + 64) * NACC + k], a3 = partials[(b + 96) * NACC + k];
+            v = (((v + a0) + a1) + a2) + a3;
+        }
+        for (; b < nblocks; b += 32) v += partials[b * NACC + k];
+    }
     stage[k][g] = v;
     __syncthreads();
     if (threadIdx.x < NACC) {
@@ -694,37 +628,50 @@ __global__ void transform_k(const float *__restrict__ pts, const int32_t *__rest
 // x = (H + damp I)^-1 g.  H, g arrive in fp32 and the damping is added in fp32 like the reference
 // (odometry/icputils.py:86-87); the 6x6 system itself is solved in fp64 with partial pivoting, which
 // removes the solver's own rounding from the parity budget (the reference inverts in fp32 LAPACK).
-__device__ void solve6_lu(const float *H, const float *g, float damp, float *x) {
-    double M[6][7];
+// The augmented matrix lives in caller-provided memory (LDS in the kernels: dynamic indexing there costs neither
+// registers nor scratch -- this rare path must not inflate the register budget of the association kernel).
+__device__ __noinline__ void solve6_lu(const float *H, const float *g, float damp, float *x, double *Mbuf /* 42 */) {
+    double (*M)[7] = reinterpret_cast<double (*)[7]>(Mbuf);
+    // every loop stays a loop (#pragma nounroll): this is the rare path, it must stay small in registers
+#pragma nounroll
     for (int i = 0; i < 6; ++i) {
+#pragma nounroll
         for (int j = 0; j < 6; ++j) M[i][j] = (double)(i == j ? H[6 * i + j] + damp : H[6 * i + j]);
         M[i][6] = (double)g[i];
     }
+#pragma nounroll
     for (int c = 0; c < 6; ++c) {
         int p = c;
         double big = fabs(M[c][c]);
+#pragma nounroll
         for (int r = c + 1; r < 6; ++r)
             if (fabs(M[r][c]) > big) { big = fabs(M[r][c]); p = r; }
-        if (p != c)
+        if (p != c) {
+#pragma nounroll
             for (int k = 0; k < 7; ++k) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
+        }
         const double piv = M[c][c];
+#pragma nounroll
         for (int r = c + 1; r < 6; ++r) {
             const double f = M[r][c] / piv;
+#pragma nounroll
             for (int k = c; k < 7; ++k) M[r][k] -= f * M[c][k];
         }
     }
-    double xs[6];
-    for (int r = 5; r >= 0; --r) {
+#pragma nounroll
+    for (int r = 5; r >= 0; --r) {  // the solution overwrites the right-hand side column
         double v = M[r][6];
-        for (int k = r + 1; k < 6; ++k) v -= M[r][k] * xs[k];
-        xs[r] = v / M[r][r];
+#pragma nounroll
+        for (int k = r + 1; k < 6; ++k) v -= M[r][k] * M[k][6];
+        M[r][6] = v / M[r][r];
     }
-    for (int i = 0; i < 6; ++i) x[i] = (float)xs[i];
+#pragma nounroll
+    for (int i = 0; i < 6; ++i) x[i] = (float)M[i][6];
 }
 
 // H + damp I is symmetric positive definite in every sane case (H = A^T A, damp > 0): fully unrolled
 // fp64 LDL^T in registers (~0.5 us on one lane); anything else falls back to the pivoted elimination.
-__device__ void solve6(const float *H, const float *g, float damp, float *x) {
+__device__ void solve6(const float *H, const float *g, float damp, float *x, double *lu_buf) {
     double A[6][6], d[6], y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -752,7 +699,7 @@ __device__ void solve6(const float *H, const float *g, float damp, float *x) {
         }
     }
     if (!ok) {
-        solve6_lu(H, g, damp, x);
+        solve6_lu(H, g, damp, x, lu_buf);
         return;
     }
 #pragma unroll
@@ -776,7 +723,7 @@ __device__ void solve6(const float *H, const float *g, float damp, float *x) {
 }
 
 // reference geometry/se3utils.py:77-115 (xi = [v ; omega]); small-angle branch uses V = I + w^ (sic)
-__device__ void se3_exp_dev(const float *xi, float *T) {
+__device__ __noinline__ void se3_exp_dev(const float *xi, float *T) {
     const float v0 = xi[0], v1 = xi[1], v2 = xi[2], w0 = xi[3], w1 = xi[4], w2 = xi[5];
     float Wh[9] = {0.0f, -w2, w1, w2, 0.0f, -w0, -w1, w0, 0.0f};
     const float th = sqrtf(__fmaf_rn(w2, w2, __fmaf_rn(w1, w1, w0 * w0)));
@@ -835,38 +782,70 @@ struct GradParams {
 };
 
 __device__ __forceinline__ void adopt_look(IcpState *S, const float *lin, int look_slot) {
+#pragma unroll 11
     for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
     S->p_cur = look_slot >= 0 ? look_slot : 1 - S->p_cur;
     S->b_cur = look_slot >= 0 ? look_slot : 1 - S->b_cur;
 }
 
-// Reduces the partials of the association + linearise launches that just ran and advances the LM /
-// gradLM state machine.
+// x = (H + damp I)^-1 g by ONE WAVE: Gauss-Jordan on the augmented 6x7 system in fp64, element (i, k) in
+// lane 8 i + k, rows / columns exchanged with lane permutes.  Takes ~0.5 us like a fully unrolled
+// single-lane factorisation but needs a handful of VGPRs instead of ~100, which is what lets the step live in
+// the association kernel without costing it its occupancy.  H + damp I is symmetric positive definite in
+// every sane case (H = A^T A, damp > 0): no pivoting; a pivot that is not a positive finite number hands the
+// system to the pivoted elimination below (one lane, matrix in LDS).  All 64 lanes must call this.
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    const int lo = __shfl(__double2loint(v), src, kWave), hi = __shfl(__double2hiint(v), src, kWave);
+    return __hiloint2double(hi, lo);
+}
+__device__ void solve6_wave(const float *H, const float *g, float damp, float *x, double *lu_buf) {
+    const int lane = threadIdx.x & 63, i = lane >> 3, k = lane & 7;
+    double a = 0.0;
+    if (i < 6 && k < 6) a = (double)(i == k ? H[6 * i + k] + damp : H[6 * i + k]);
+    if (i < 6 && k == 6) a = (double)g[i];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double piv = shfl_d(a, 8 * j + j);
+        ok = ok && (piv > 0.0) && (piv < 1e300);
+        const double pr = shfl_d(a, 8 * j + k);                 // pivot row, my column
+        const double col = shfl_d(a, 8 * (i < 6 ? i : 0) + j);  // my row, pivot column
+        const double inv = 1.0 / piv;
+        a = (i == j) ? pr * inv : a - (col * inv) * pr;
+    }
+    if (i < 6 && k == 6) x[i] = (float)a;
+    if (!ok && lane == 0) solve6_lu(H, g, damp, x, lu_buf);     // `ok` is wave-uniform: every lane saw the same pivots
+}
+
+// The O(1) step in three parts, so that the solve can be the wave-parallel one:
+//   step_decide (one lane): reduce result -> LM / gradLM state machine; returns whether a solve follows
+//   solve6_wave (wave 0)
+//   step_finish (one lane): dT = exp(xi)
 //   STEP_ADOPT : the look-ahead cloud becomes the current one unconditionally (initial cloud; gradICP's
 //                re-linearisation)                          -> solve ; dT = exp(xi)
 //   STEP_LM    : look-ahead cloud: accept (adopt, damp/2, T = dT T) or reject (damp*2) -> solve ; dT
 //   STEP_GRAD_B: look-ahead error -> damp, sigma ; dT = exp(sigma xi) ; T = dT T ; look-ahead discarded
-__device__ void step_update(IcpState *S, const float *acc, int mode, GradParams gp, float *__restrict__ trace,
-                            float *__restrict__ out_T, int look_slot, float *__restrict__ rec) {
-    float lin[44];
+__device__ bool step_decide(IcpState *S, const float *acc, int mode, GradParams gp, float *__restrict__ trace,
+                                         float *__restrict__ out_T, int look_slot, float *__restrict__ rec,
+                                         float *lin /* 44 floats of LDS: keeps the expansion out of the register file */) {
     expand44(acc, lin);
     if (rec) {  // tape: what the look-ahead launch measured, where it wrote, what this step is
+#pragma unroll 8
         for (int i = 0; i < 44; ++i) rec[REC_LIN + i] = lin[i];
         rec[REC_SLOT] = (float)look_slot;
         rec[REC_MODE] = (float)mode;
         rec[REC_ACCEPT] = (mode == STEP_LM) ? ((lin[42] < S->cur[42]) ? 1.0f : 0.0f) : 1.0f;
     }
-
+    bool solve = true;
     if (mode == STEP_ADOPT) {
         adopt_look(S, lin, look_slot);
         S->b_first = S->b_cur;
-        solve6(S->cur, S->cur + 36, S->damp, S->xi);
-        se3_exp_dev(S->xi, S->dT);
     } else if (mode == STEP_LM) {
         const float err = S->cur[42], new_err = lin[42];
         const bool accept = new_err < err;
         if (trace) {
             float *t = trace + 48 * S->it;
+#pragma unroll 8
             for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
             t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = accept ? 1.0f : 0.0f; t[46] = S->cur[43];
             t[47] = 0.0f;
@@ -880,14 +859,6 @@ __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams 
             S->damp = S->damp * 2.0f;  // the look-ahead buffers are simply overwritten next time
         }
         S->it += 1;
-#ifdef GS_DIAG_STAMPS
-        if (g_diag) g_diag[3] = wall_clock64();
-#endif
-        solve6(S->cur, S->cur + 36, S->damp, S->xi);
-#ifdef GS_DIAG_STAMPS
-        if (g_diag) g_diag[4] = wall_clock64();
-#endif
-        se3_exp_dev(S->xi, S->dT);
     } else {  // STEP_GRAD_B
         const float err = S->cur[42], new_err = lin[42];
         float diff = new_err - err;
@@ -895,27 +866,50 @@ __device__ void step_update(IcpState *S, const float *acc, int mode, GradParams 
         const float damp_new = gp.lambda_min + gp.range / (1.0f + expf((-gp.B) * diff));
         if (trace) {
             float *t = trace + 48 * S->it;
+#pragma unroll 8
             for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
             t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = 1.0f; t[46] = S->cur[43]; t[47] = 0.0f;
         }
         S->b_first = S->b_cur;
         S->damp = S->damp * damp_new;
         const float sig = 1.0f / powf(1.0f + expf((-gp.B2) * diff), gp.inv_nu);
-        float sx[6];
+        float *sx = lin;  // LDS scratch again (lin is dead by now): no stack for the non-inlined exp
+#pragma unroll 8
         for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
         se3_exp_dev(sx, S->dT);
         mm4(S->dT, S->T, S->T);
         S->it += 1;  // the next launch re-derives the cloud from pts[p_cur] with the damped step
+        solve = false;
     }
-    if (out_T)
+    if (out_T) {
+#pragma unroll 8
         for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
+    }
+    return solve;
+}
+
+// Whole step by a block (>= 64 threads, all of them call this): S and acc in LDS.  `solve` = false for a loop's
+// very last step, whose xi / dT nothing consumes.
+__device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mode, GradParams gp, float *trace, float *out_T,
+                                           int look_slot, float *rec, double *lu_buf, bool solve) {
+    __shared__ int need_solve;
+    __shared__ float lin_sm[44];
+    if (threadIdx.x == 0) need_solve = (step_decide(S, acc, mode, gp, trace, out_T, look_slot, rec, lin_sm) && solve) ? 1 : 0;
+    __syncthreads();
+    if (need_solve) {  // block-uniform
+        if (threadIdx.x < 64) solve6_wave(S->cur, S->cur + 36, S->damp, S->xi, lu_buf);
+        __syncthreads();
+        if (threadIdx.x == 0) se3_exp_dev(S->xi, S->dT);
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
                                                   int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
                                                   float *__restrict__ out_T, int look_slot,
-                                                  float *__restrict__ rec /* this step's tape record or NULL */) {
+                                                  float *__restrict__ rec /* this step's tape record or NULL */, int solve) {
     __shared__ float acc[NACC];
+    __shared__ double lu_sm[42];
     __shared__ IcpState st;  // work on an LDS copy: ~200 dependent accesses at LDS, not HBM, latency
     constexpr int kWords = sizeof(IcpState) / 4;
 #ifdef GS_DIAG_STAMPS
@@ -927,7 +921,7 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[1] = wall_clock64();
 #endif
-    if (threadIdx.x == 0) step_update(&st, acc, mode, gp, trace, out_T, look_slot, rec);
+    step_block(&st, acc, mode, gp, trace, out_T, look_slot, rec, lu_sm, solve != 0);
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[2] = wall_clock64();
 #endif
@@ -939,14 +933,159 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
     }
 }
 
-__global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T, float damp) {
+// Association launch of the loops, with the PRECEDING step folded into its prologue.
+// A tiny dependent kernel costs ~4.5 us of stream time on this part however little it computes, so the loop's
+// O(1) step (reduce the previous launch's partial sums, LM / gradLM decision, 6x6 solve, exp) is not a launch
+// of its own: every block of the next association recomputes it from the previous launch's outputs (S_in,
+// partials_in -- complete and visible at kernel start, no inter-block hand-off inside a launch) into LDS, and
+// block 0 alone publishes the new state (S_out, tape record, trace, out_T).  State and partial sums are
+// double-buffered across launches so that no block reads what another block of the same launch writes.
+// Then: in = (first ? user source : pts[p_cur]) transformed by dT, out = pts[out_slot], NN -> best[out_slot]
+// (out_slot < 0: the other one of the two ping-pong slots).  Seed: the current cloud's NN of the same source index
+// when there is one, else the sampled seed pass.
+__global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
+                                                      const float *__restrict__ partials_in, int nblocks_in, int step_mode,
+                                                      GradParams gp, float *__restrict__ trace, float *__restrict__ out_T,
+                                                      int look_slot, float *__restrict__ rec, int first, int out_slot,
+                                                      const float *__restrict__ user_src, LoopBufs B,
+                                                      const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                                                      const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
+                                                      const float *__restrict__ nrm, float thresh,
+                                                      float *__restrict__ partials /* gridDim.x x NACC */,
+                                                      gs_icp_hints hints) {
+    __shared__ KnnShared sh;
+    __shared__ IcpState st_sm;
+    __shared__ float acc_sm[NACC];
+    __shared__ double lu_sm[42];
+    constexpr int kWords = sizeof(IcpState) / 4;
+    if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
+    if (step_mode >= 0) {
+        const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
+        reduce_partials(partials_in, nblocks_in, acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
+        if (pub && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(&st_sm)[threadIdx.x];
+        step_block(&st_sm, acc_sm, step_mode, gp, pub ? trace : nullptr, pub ? out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm,
+                   true);  // ends with a barrier
+        if (pub && threadIdx.x < kWords) {
+            const int v = reinterpret_cast<const int *>(&st_sm)[threadIdx.x];
+            reinterpret_cast<int *>(S_out)[threadIdx.x] = v;
+            if (rec) reinterpret_cast<int *>(rec)[REC_WORDS + REC_STATE + threadIdx.x] = v;
+        }
+    } else {
+        __syncthreads();
+    }
+    const IcpState *S = &st_sm;
+    const int ns = *d_ns, nt = *d_nt;
+    const int tile0 = blockIdx.x * 64;
+    if (tile0 >= ns) {  // empty tile: its partial row must still be defined
+        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
+        return;
+    }
+    const int p_cur = S->p_cur, b_cur = S->b_cur;
+    const float *in = first ? user_src : B.P(p_cur);
+    float *out = B.P(out_slot >= 0 ? out_slot : 1 - p_cur);
+    unsigned long long *best = B.N(out_slot >= 0 ? out_slot : 1 - b_cur);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = tile0 + lane;
+    const bool ok = i < ns;
+    f3 s{0.0f, 0.0f, 0.0f};
+    if (ok) {
+        s = xform(S->dT, ld3(in, i));
+        if (wave == 0) st3(out, i, s);
+    }
+    if (nt <= 0) {
+        if (ok && wave == 0) best[i] = KEY_NONE;
+        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
+        return;
+    }
+    int sj = -1;
+    if (!first) {
+        sj = 0;
+        if (ok) {
+            const unsigned long long k = B.N(b_cur)[i];
+            sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
+        }
+    }
+    const bool window_seed = first && hints.scan_points && hints.src_pix && hints.pix_start && hints.grid_w > 0;
+    if (window_seed) sj = -2;  // seeded by knn_window_seed below (block-uniform decision)
+    const float *scan = hints.scan_points ? hints.scan_points : tgt;
+    const int32_t *scan_orig = hints.scan_points ? hints.scan_orig : nullptr;
+    if (window_seed) knn_window_seed(sh, s, ok, i, hints, nt);
+    const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, scan, scan_orig, boxes, nt);
+    // linearise this tile straight away (J fused into K's epilogue): 29 sums over the tile's 64 points,
+    // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
+    if (wave == 0) {
+        if (ok) best[i] = key;
+        float acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+        const Row r = make_row_from(s, ok, key, tgt, nrm, thresh);
+        if (r.valid) accumulate_row(r, acc);
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) sh.rows[k][lane] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC * 16) {
+        const int k = threadIdx.x >> 4, p4 = (threadIdx.x & 15) * 4;
+        sh.part[k][threadIdx.x & 15] = ((sh.rows[k][p4] + sh.rows[k][p4 + 1]) + sh.rows[k][p4 + 2]) + sh.rows[k][p4 + 3];
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += sh.part[threadIdx.x][q];
+        partials[blockIdx.x * NACC + threadIdx.x] = v;
+    }
+}
+
+__global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T /* NULL = identity */, float damp) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int i = 0; i < 16; ++i) { S->T[i] = init_T[i]; S->dT[i] = init_T[i]; }
+        for (int i = 0; i < 16; ++i) {
+            const float v = init_T ? init_T[i] : ((i % 5 == 0) ? 1.0f : 0.0f);
+            S->T[i] = v; S->dT[i] = v;
+        }
         for (int i = 0; i < 44; ++i) S->cur[i] = 0.0f;
         S->damp = damp;
         S->p_cur = 1;  // the first association writes pts[0] / best[0]
         S->b_cur = 1; S->b_first = 0;
         S->it = 0;
+    }
+}
+
+// one launch for the loop's two preparations: initial state (one lane) and the target's chunk boxes
+__global__ __launch_bounds__(64) void icp_prepare_k(IcpState *S, const float *__restrict__ init_T, float damp,
+                                                    const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
+                                                    float *__restrict__ boxes) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 16; ++i) {
+            const float v = init_T ? init_T[i] : ((i % 5 == 0) ? 1.0f : 0.0f);
+            S->T[i] = v; S->dT[i] = v;
+        }
+        for (int i = 0; i < 44; ++i) S->cur[i] = 0.0f;
+        for (int i = 0; i < 6; ++i) S->xi[i] = 0.0f;
+        S->damp = damp;
+        S->p_cur = 1;  // the first association writes pts[0] / best[0]
+        S->b_cur = 1; S->b_first = 0;
+        S->it = 0;
+    }
+    const int nt = *d_nt;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= nt) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (j < nt) {
+        const f3 p = ld3(tgt, j);
+        lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = CHUNK / 2; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, kWave));
+        }
+    }
+    if ((threadIdx.x % CHUNK) == 0 && j < nt) {
+        float *b = boxes + 6 * (int64_t)(j / CHUNK);
+        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
     }
 }
 
@@ -1002,27 +1141,27 @@ static inline void prof_mark(int tag, int which, hipStream_t st) {
 bool profiling_enabled() { return g_prof.on; }
 
 struct IcpWs {
-    IcpState *S;
+    IcpState *S[2];      // double-buffered across launches (see knn1_loop_k)
     LoopBufs B;
-    float *partials;
+    float *partials[2];
     float *boxes;
 };
 static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    const size_t oS = take(sizeof(IcpState));
+    const size_t oS = take(sizeof(IcpState)), oS1 = take(sizeof(IcpState));
     const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
-    const size_t oPart = take((size_t)cdiv(max_ns, 64) * NACC * 4);
+    const size_t oPart = take((size_t)cdiv(max_ns, 64) * NACC * 4), oPart1 = take((size_t)cdiv(max_ns, 64) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt));
     if (ws && out) {
         char *p = (char *)ws;
-        out->S = (IcpState *)(p + oS);
+        out->S[0] = (IcpState *)(p + oS); out->S[1] = (IcpState *)(p + oS1);
         out->B.pts = (float *)(p + oP0);
         out->B.pts_stride = (int64_t)(oP1 - oP0) / 4;
         out->B.best = (unsigned long long *)(p + oB0);
         out->B.best_stride = (int64_t)(oB1 - oB0) / 8;
-        out->partials = (float *)(p + oPart);
+        out->partials[0] = (float *)(p + oPart); out->partials[1] = (float *)(p + oPart1);
         out->boxes = (float *)(p + oBox);
     }
     return off;
@@ -1060,14 +1199,19 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
-    GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && init_T && out_T, "%s: NULL argument", name);
+    GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && out_T, "%s: NULL argument", name);  // init_T NULL = identity
     GS_REQUIRE(max_ns > 0 && max_nt > 0 && numiters >= 0, "%s: bad sizes max_ns=%d max_nt=%d numiters=%d", name, max_ns, max_nt, numiters);
     if (!ws || ws_bytes < icp_ws_layout(max_ns, max_nt, nullptr, nullptr)) {
         set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, icp_ws_layout(max_ns, max_nt, nullptr, nullptr));
         return GS_ERR_WORKSPACE_TOO_SMALL;
     }
     if (numiters == 0) {
-        GS_HIP(hipMemcpyAsync(out_T, init_T, 64, hipMemcpyDeviceToDevice, st), name);
+        if (init_T) {
+            GS_HIP(hipMemcpyAsync(out_T, init_T, 64, hipMemcpyDeviceToDevice, st), name);
+        } else {
+            hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, (IcpState *)ws, init_T, damp);
+            GS_HIP(hipMemcpyAsync(out_T, ws, 64, hipMemcpyDeviceToDevice, st), name);  // IcpState starts with T
+        }
         return GS_OK;
     }
     IcpWs w;
@@ -1086,22 +1230,40 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int lb = (int)kgrid.x;  // one partial row per 64-point tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
 
-    hipLaunchKernelGGL(icp_init_state_k, dim3(1), dim3(64), 0, st, w.S, init_T, damp);
-    hipLaunchKernelGGL(tgt_boxes_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, hints.scan_points ? hints.scan_points : tgt, d_nt,
-                       w.boxes);
+    hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, w.S[0], init_T, damp,
+                       hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes);
     GS_LAUNCH_CHECK(name);
+    // The loop as a sequence  A S A S ... A S  (A = association + linearise launch, S = O(1) step on A's sums).
+    // Every S but the last runs in the prologue of the A that follows it; state and partial sums alternate
+    // between two buffers from launch to launch.
+    int cur = 0;            // buffer the next launch READS its state / the previous sums from
+    int pending = -1;       // step waiting to be folded into the next association
+    int pending_slot = -1;  // slot the association before that step wrote (tape mode)
     auto assoc = [&](int first) {
+        const int nxt = pending >= 0 ? 1 - cur : cur;  // a folded step publishes the new state to the other buffer
         prof_mark(0, 0, st);
-        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S, first, tape ? n_assoc : -1, src, w.B, d_ns, tgt,
-                           w.boxes, d_nt, nrm, thresh, w.partials, hints);
-        ++n_assoc;
+        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S[cur], w.S[nxt], w.partials[cur], lb, pending, gp, trace,
+                           out_T, pending_slot, (tape && pending >= 0) ? tp.rec + (size_t)n_step * REC_WORDS : nullptr, first,
+                           tape ? n_assoc : -1, src, w.B, d_ns, tgt, w.boxes, d_nt, nrm, thresh, w.partials[nxt], hints);
         prof_mark(0, 1, st);
+        if (pending >= 0) ++n_step;
+        cur = nxt;
+        pending = -1;
+        ++n_assoc;
     };
-    auto step = [&](int mode) {
-        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S, w.partials, lb, mode, gp, trace, out_T,
-                           tape ? n_assoc - 1 : -1, tape ? tp.rec + (size_t)n_step * REC_WORDS : nullptr);
+    auto step = [&](int mode) {  // deferred: folded into the next association, or launched by finish()
+        pending = mode;
+        pending_slot = tape ? n_assoc - 1 : -1;
+    };
+    auto finish = [&]() {  // the loop's last step has no association behind it
+        hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S[cur], w.partials[cur], lb, pending, gp, trace, out_T,
+                           pending_slot, tape ? tp.rec + (size_t)n_step * REC_WORDS : nullptr, 0);
         ++n_step;
+        pending = -1;
     };
+    // NB with a folded step the sums it reduces are those of the launch before: partials[cur] at that time.
+    // assoc() above passes w.partials[cur] (read) and w.partials[nxt] (write); without a pending step nothing is
+    // read and cur == nxt is harmless.
     assoc(1);
     step(STEP_ADOPT);
     if (!grad) {
@@ -1121,9 +1283,10 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
             }
         }
     }
+    finish();
     GS_LAUNCH_CHECK(name);
     if (best_last) {
-        hipLaunchKernelGGL(copy_best_last_k, dim3(fb), dim3(256), 0, st, w.S, w.B, d_ns, (unsigned long long *)best_last);
+        hipLaunchKernelGGL(copy_best_last_k, dim3(fb), dim3(256), 0, st, w.S[cur], w.B, d_ns, (unsigned long long *)best_last);
         GS_LAUNCH_CHECK(name);
     }
     return GS_OK;
@@ -1376,8 +1539,9 @@ __device__ __forceinline__ void pull_gT(float *gT, const float *dT) {  // gT <- 
 // xi = (H + damp I)^-1 g : given gxi -> G (Hbar, gbar), returns damp_bar
 __device__ double solve_bwd(const float *H, float damp, const float *xi, const double *gxi, float *G) {
     float gx[6], y[6];
+    double lu[42];
     for (int i = 0; i < 6; ++i) gx[i] = (float)gxi[i];
-    solve6(H, gx, damp, y);  // M symmetric: M^-T = M^-1
+    solve6(H, gx, damp, y, lu);  // M symmetric: M^-T = M^-1
     double gd = 0.0;
     for (int i = 0; i < 6; ++i) {
         for (int j = 0; j < 6; ++j) G[6 * i + j] = -y[i] * xi[j];

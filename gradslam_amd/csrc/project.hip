@@ -189,9 +189,21 @@ __global__ void pix_scatter_k(const int64_t *__restrict__ rows, const int32_t *_
 }
 // fused front of the ICP target build: reference-order gather of points + normals AND the per-pixel
 // histogram / seed in one pass over the table rows
-__global__ void tgt_init_k(int *__restrict__ cnt, int *__restrict__ fill, int64_t n) {
+// zeroes the per-pixel counters AND finds the per-batch row ranges (two independent preparations, one launch)
+__global__ void tgt_init_k(int *__restrict__ cnt, int *__restrict__ fill, int64_t n, const int64_t *__restrict__ rows,
+                           const int32_t *__restrict__ d_n, int B, int32_t *__restrict__ starts) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         cnt[i] = 0; fill[i] = 0;
+    }
+    if (blockIdx.x == 0) {
+        for (int b = threadIdx.x; b <= B; b += blockDim.x) {
+            int lo = 0, hi = *d_n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (rows[4 * (int64_t)mid] < b) lo = mid + 1; else hi = mid;
+            }
+            starts[b] = lo;
+        }
     }
 }
 __global__ void tgt_gather_count_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
@@ -292,8 +304,7 @@ int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max
     const size_t seg = align_up((size_t)B * npix * 4, 256);
     int *cnt = (int *)p, *fill = (int *)(p + seg);
     const int64_t nbins = (int64_t)B * npix;
-    hipLaunchKernelGGL(tgt_init_k, dim3(min(cdiv(nbins, 256), 1024)), dim3(256), 0, st, cnt, fill, nbins);
-    hipLaunchKernelGGL(table_starts_k, dim3(cdiv(B + 1, 64)), dim3(64), 0, st, rows, d_n_rows, B, starts);
+    hipLaunchKernelGGL(tgt_init_k, dim3(min(cdiv(nbins, 256), 1024)), dim3(256), 0, st, cnt, fill, nbins, rows, d_n_rows, B, starts);
     const int nb = max_rows > 0 ? min(cdiv(max_rows, 256), 1024) : 1;
     hipLaunchKernelGGL(pix_count_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, cnt);
     hipLaunchKernelGGL(pix_scan_k, dim3(B), dim3(1024), 0, st, cnt, npix, pix_start);
@@ -323,8 +334,7 @@ int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t ma
     const size_t seg = align_up((size_t)B * npix * 4, 256);
     int *cnt = (int *)p, *fill = (int *)(p + seg);
     const int64_t nbins = (int64_t)B * npix;
-    hipLaunchKernelGGL(tgt_init_k, dim3(min(cdiv(nbins, 256), 1024)), dim3(256), 0, st, cnt, fill, nbins);
-    hipLaunchKernelGGL(table_starts_k, dim3(cdiv(B + 1, 64)), dim3(64), 0, st, rows, d_n_rows, B, starts);
+    hipLaunchKernelGGL(tgt_init_k, dim3(min(cdiv(nbins, 256), 1024)), dim3(256), 0, st, cnt, fill, nbins, rows, d_n_rows, B, starts);
     const int nb = max_rows > 0 ? min(cdiv(max_rows, 256), 1024) : 1;
     hipLaunchKernelGGL(tgt_gather_count_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, map_points, map_normals, B, Nmax,
                        cap, tgt, tgt_normals, counts, Wd, npix, ds, cnt, tgt_index);

@@ -288,8 +288,6 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     // per ds-grid pixel (search hints only)
     if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
                                   w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.sub, w.sub_bytes, stream))) return rc;
-    hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
-    GS_LAUNCH_CHECK("gs_slam_localize/eye");
     auto enqueue_loops = [&](gs_stream_t s) -> int {
         for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
             const float *src = w.src + (size_t)b * capS * 3;
@@ -298,11 +296,11 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
                                      w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
             int r;
             if (use_grad_lm)
-                r = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                r = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, nullptr /* identity */, numiters, damp,
                                                dist_thresh, lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, nullptr, nullptr, w.sub,
                                                w.sub_bytes, s);
             else
-                r = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                r = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, nullptr /* identity */, numiters, damp,
                                           dist_thresh, &hints, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, s);
             if (r) return r;
         }
@@ -435,7 +433,6 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
     }
     GS_REQUIRE(tape_bytes >= gs_slam_localize_tape_bytes(B, H, W, ds, Nmax, numiters, use_grad_lm),
                "gs_slam_localize_taped: tape too small");
-    hipStream_t st = (hipStream_t)stream;
     LocWs w;
     loc_layout(B, H, W, ds, Nmax, ws, &w);
     LocTape tp;
@@ -448,13 +445,11 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
                                 w.sub_bytes, stream))) return rc;
     if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
                                   w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.sub, w.sub_bytes, stream))) return rc;
-    hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, w.eye, B);
-    GS_LAUNCH_CHECK("gs_slam_localize_taped/eye");
     for (int b = 0; b < B; ++b) {
         const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, tp.src_pix + (size_t)b * capS,
                                  w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
         if ((rc = gs_icp_point_to_plane_taped(tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
-                                              w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, w.eye + 16 * b, numiters, damp,
+                                              w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, nullptr /* identity */, numiters, damp,
                                               dist_thresh, use_grad_lm, lambda_max, Bp, B2, nu, &hints, tp.T + 16 * b, nullptr,
                                               tp.icp + (size_t)b * tp.icp_bytes, tp.icp_bytes, w.sub, w.sub_bytes, stream)))
             return rc;

@@ -213,7 +213,7 @@ int gs_transform_points(const float *pts, const int32_t *d_n, int max_n, const f
 
 /* ---------------------------------------------------------------- X: whole ICP loops on device
  * point_to_plane_ICP (odometry/icputils.py:310-367): LM loop with the accept/reject decision kept
- * on the device.  src (ns,3), tgt/normals (nt,3), init_T (device 4x4).  Outputs: T (device 4x4),
+ * on the device.  src (ns,3), tgt/normals (nt,3), init_T (device 4x4; NULL = identity).  Outputs: T (device 4x4),
  * optional best_last (packed NN of the last iteration's first solve) and optional trace
  * (numiters x 48 floats: H36|g6|err|new_err|damp|accept|cnt|pad).  dist_thresh < 0 == None. */
 /* Optional search hints (NULL, or any member NULL, = none).  They never change a result: the
