@@ -518,14 +518,18 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // blockDim.x == 1024 -> g in [0, 32)
     float v = 0.0f;
     if (k < NACC) {
-        // four independent loads in flight per round (the rows are L2-resident; latency, not bandwidth, is the cost)
-        int b = g;
-        for (; b + 96 < nblocks; b += 128) {
-            const float a0 = partials[b * NACC + k], a1 = partials[(b + 32) * NACC + k];
-            const float a2 = partials[(b + 64) * NACC + k], a3 = partials[(b + 96) * NACC + k];
-            v = (((v + a0) + a1) + a2) + a3;
+        // The rows were written by the previous launch on other CUs: every read is a trip to memory-side
+        // cache (~1.5 us), so what matters is how many of them are in flight -- ten per thread and round.
+        for (int b0 = g; b0 < nblocks; b0 += 320) {
+            float a[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int b = b0 + 32 * u;
+                a[u] = b < nblocks ? partials[b * NACC + k] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v += a[u];
         }
-        for (; b < nblocks; b += 32) v += partials[b * NACC + k];
     }
     stage[k][g] = v;
     __syncthreads();
@@ -958,6 +962,7 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
     __shared__ float acc_sm[NACC];
     __shared__ double lu_sm[42];
     constexpr int kWords = sizeof(IcpState) / 4;
+    GS_STAMP(6);
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
     if (step_mode >= 0) {
         const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
@@ -973,6 +978,7 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
     } else {
         __syncthreads();
     }
+    GS_STAMP(7);
     const IcpState *S = &st_sm;
     const int ns = *d_ns, nt = *d_nt;
     const int tile0 = blockIdx.x * 64;

@@ -53,6 +53,12 @@ dbg.zero_()
 T, _, _ = ops.icp_device_loop(src, tgt, nrm, torch.eye(4, device=dev), 10, 1e-8, None)
 torch.cuda.synchronize()
 report("last association of a 10-iteration ICP loop (seeded by the previous neighbour)")
+a = dbg.cpu().numpy().reshape(nblk, 16, 8).astype(np.float64)
+t6, t7, t0, t3 = a[..., 6], a[..., 7], a[..., 0], a[..., 3]
+print("folded step (prologue) us per wave: p50 %.2f p99 %.2f ; prologue end -> search start p50 %.2f ; search p50 %.2f ; kernel entry spread p99 %.2f" % (
+    *np.percentile((t7 - t6) * 0.01, [50, 99]), np.percentile((t0 - t7) * 0.01, 50), np.percentile((t3 - t0) * 0.01, 50),
+    np.percentile((t6 - t6.min()) * 0.01, 99)))
+print("kernel span incl. prologue us %.1f" % ((t3.max() - t6.min()) * 0.01))
 # step-kernel stamps live in slots 0..4 of the buffer; rerun the loop with a separate small buffer
 dbg2 = torch.zeros(8, dtype=torch.int64, device=dev)
 assert lib.gs_diag_set_buffer(dbg2.data_ptr()) == 0
