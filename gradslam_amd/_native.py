@@ -134,7 +134,16 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw handle of torch's current HIP stream on the current device.  The raw accessors cost well under a
+    microsecond; torch.cuda.current_stream() builds a Stream object (~10 us), which matters at ~80 us of host
+    time per localisation step."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
