@@ -19,9 +19,10 @@
 //    with one 64-bit atomic min per (point, range) on the packed key  dist_bits<<32 | index.
 // J  gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; wave
 //    butterflies + a fixed-order two-level tree (deterministic, no float atomics).
-// X  one small workgroup per iteration: reduce the partials, LM / gradLM decision, fp64 6x6 solve,
-//    SE(3) exponential.  Buffers are addressed through device-side role indices, so accept/reject needs
-//    no host round trip and no copies.
+// X  the O(1) step of an iteration (reduce the partials, LM / gradLM decision, fp64 6x6 solve, SE(3)
+//    exponential) runs in the prologue of the NEXT association launch, recomputed by every block, published by
+//    block 0; only a loop's last step is a launch of its own.  Buffers are addressed through device-side role
+//    indices, so accept/reject needs no host round trip and no copies.
 #include <vector>
 
 #include "gs_common.hpp"
