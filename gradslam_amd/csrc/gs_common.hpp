@@ -65,6 +65,16 @@ __device__ __forceinline__ void st3(float *__restrict__ p, int64_t i, f3 v) {
 
 // K=3 contraction in the order the reference's CPU GEMM was measured to use:
 //   fma(a2, b2, fma(a1, b1, a0 * b0))
+__device__ __forceinline__ float dot3_fma(float a0, float a1, float a2, float b0, float b1, float b2);
+// kornia.geometry.linalg.compose_transformations semantics (call site reference slam/icpslam.py:245-247):
+// R = R01 R12 ; t = R01 t12 + t01 ; bottom row [0,0,0,1].   o = a . p   (4x4 row-major each)
+__device__ __forceinline__ void compose44(const float *a, const float *p, float *o) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) o[4 * i + j] = dot3_fma(a[4 * i], a[4 * i + 1], a[4 * i + 2], p[j], p[4 + j], p[8 + j]);
+        o[4 * i + 3] = dot3_fma(a[4 * i], a[4 * i + 1], a[4 * i + 2], p[3], p[7], p[11]) + a[4 * i + 3];
+    }
+    o[12] = 0.0f; o[13] = 0.0f; o[14] = 0.0f; o[15] = 1.0f;
+}
 __device__ __forceinline__ float dot3_fma(float a0, float a1, float a2, float b0, float b1, float b2) {
     return __fmaf_rn(a2, b2, __fmaf_rn(a1, b1, a0 * b0));
 }

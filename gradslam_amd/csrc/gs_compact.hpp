@@ -22,6 +22,12 @@ template <class W, class = void>
 struct writer_has_skip : std::false_type {};
 template <class W>
 struct writer_has_skip<W, std::void_t<decltype(&W::skip)>> : std::true_type {};
+// a Pred may provide block_init(), run once by every block of both passes before the first item (followed by a
+// barrier): per-block constants go to LDS there instead of costing a preparation launch
+template <class P, class = void>
+struct pred_has_block_init : std::false_type {};
+template <class P>
+struct pred_has_block_init<P, std::void_t<decltype(&P::block_init)>> : std::true_type {};
 
 constexpr int kCT = 256;               // threads per block
 constexpr int kCI = 4;                 // consecutive items per thread
@@ -34,6 +40,10 @@ static inline size_t compact_ws_bytes(int64_t n) { return align_up(2 * sizeof(in
 template <class Pred>
 __global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts) {
     __shared__ int sm[kCT / 64];
+    if constexpr (pred_has_block_init<Pred>::value) {
+        pred.block_init();
+        __syncthreads();
+    }
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     int c = 0;
 #pragma unroll
@@ -113,6 +123,10 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
                                                        const int *__restrict__ block_offsets /* SelfScan: block COUNTS */,
                                                        int *__restrict__ out_total = nullptr) {
     __shared__ int sm[kCT / 64 + 1];
+    if constexpr (pred_has_block_init<Pred>::value) {
+        pred.block_init();
+        __syncthreads();
+    }
     const int block_base = SelfScan ? self_scan_offset(block_offsets, out_total) : block_offsets[blockIdx.x];
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     bool f[kCI];

@@ -912,7 +912,8 @@ __device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mo
 __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
                                                   int mode, GradParams gp, float *__restrict__ trace /* or NULL */,
                                                   float *__restrict__ out_T, int look_slot,
-                                                  float *__restrict__ rec /* this step's tape record or NULL */, int solve) {
+                                                  float *__restrict__ rec /* this step's tape record or NULL */, int solve,
+                                                  const float *__restrict__ compose_right, float *__restrict__ compose_out) {
     __shared__ float acc[NACC];
     __shared__ double lu_sm[42];
     __shared__ IcpState st;  // work on an LDS copy: ~200 dependent accesses at LDS, not HBM, latency
@@ -936,6 +937,7 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
         reinterpret_cast<int *>(Sg)[threadIdx.x] = v;
         if (rec) reinterpret_cast<int *>(rec)[REC_WORDS + REC_STATE + threadIdx.x] = v;  // head of the next record = state after
     }
+    if (compose_out && threadIdx.x == 0) compose44(st.T, compose_right, compose_out);  // e.g. T . previous pose
 }
 
 // Association launch of the loops, with the PRECEDING step folded into its prologue.
@@ -1202,7 +1204,8 @@ static inline size_t tape_layout(bool grad, int max_ns, int numiters, void *tape
 static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                    const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp, float thresh,
                    GradParams gp, const gs_icp_hints *hints_in, float *out_T, uint64_t *best_last, float *trace, void *ws,
-                   size_t ws_bytes, hipStream_t st, const char *name, void *tape = nullptr, size_t tape_bytes = 0) {
+                   size_t ws_bytes, hipStream_t st, const char *name, void *tape = nullptr, size_t tape_bytes = 0,
+                   const float *compose_right = nullptr, float *compose_out = nullptr) {
     gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
@@ -1264,7 +1267,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     };
     auto finish = [&]() {  // the loop's last step has no association behind it
         hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S[cur], w.partials[cur], lb, pending, gp, trace, out_T,
-                           pending_slot, tape ? tp.rec + (size_t)n_step * REC_WORDS : nullptr, 0);
+                           pending_slot, tape ? tp.rec + (size_t)n_step * REC_WORDS : nullptr, 0, compose_right, compose_out);
         ++n_step;
         pending = -1;
     };
@@ -1717,6 +1720,17 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
     hipLaunchKernelGGL(bwd_finish_k, dim3(nb), dim3(BWD_T), 0, st, init_T, d_ns, w.gP, g_src);
     GS_LAUNCH_CHECK(name);
     return GS_OK;
+}
+
+int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
+                     const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
+                     float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out) {
+    const GradParams gp = grad_lm ? GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max),
+                                               Bp, B2, (float)(1.0 / (double)nu)}
+                                  : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f};
+    return icp_run(grad_lm != 0, src, d_ns, max_ns, tgt, nrm, d_nt, max_nt, nullptr, numiters, damp, thresh, gp, hints, out_T, nullptr,
+                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out);
 }
 
 }  // namespace gs

@@ -16,6 +16,27 @@ struct Cam {
 
 // One Cam per batch element, computed on device (no host math, no sync).
 // inverse_transformation semantics (R^T, -R^T t); the small batched matmul(-R^T, t) does not fuse.
+__device__ __forceinline__ Cam make_cam(const float *__restrict__ T, const float *__restrict__ K) {
+    Cam c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.R[3 * i + j] = T[4 * i + j];
+    const float t0 = T[3], t1 = T[7], t2 = T[11];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c.tinv[j] = ((-T[j]) * t0 + (-T[4 + j]) * t1) + (-T[8 + j]) * t2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c.K[i] = K[i];
+    return c;
+}
+// per-block LDS copy of the cameras (up to kCamB batch elements): filled by ActivePred::block_init in both
+// compaction passes, so the projection needs no preparation launch
+constexpr int kCamB = 32;
+__device__ __forceinline__ Cam *cam_cache() {
+    __shared__ Cam cams[kCamB];
+    return cams;
+}
+
 __global__ void build_cams_k(const float *__restrict__ poses, const float *__restrict__ Ks, int B, Cam *__restrict__ cams) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -86,6 +107,39 @@ struct ActiveWriter {
         const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
         int h, w;
         project_point(cams[b], ld3(points, i), H, W, umax, vmax, h, w);
+        longlong4 r;  // one 32-byte store per row
+        r.x = b; r.y = n; r.z = h; r.w = w;
+        *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
+    }
+};
+
+// the same pair with the cameras built per block in LDS (B <= kCamB)
+struct ActivePredL {
+    const float *points;
+    const int32_t *counts;
+    const float *poses, *Ks;
+    int B, Nmax, H, W, ds;
+    float umax, vmax;
+    __device__ void block_init() const {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) cam_cache()[b] = make_cam(poses + 16 * b, Ks + 16 * b);
+    }
+    __device__ bool operator()(int64_t i) const {
+        const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
+        if (n >= counts[b]) return false;
+        int h, w;
+        if (!project_point(cam_cache()[b], ld3(points, i), H, W, umax, vmax, h, w)) return false;
+        return ds <= 0 || ((h % ds == 0) && (w % ds == 0));
+    }
+};
+struct ActiveWriterL {
+    const float *points;
+    int64_t *rows;
+    int Nmax, H, W;
+    float umax, vmax;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
+        int h, w;
+        project_point(cam_cache()[b], ld3(points, i), H, W, umax, vmax, h, w);
         longlong4 r;  // one 32-byte store per row
         r.x = b; r.y = n; r.z = h; r.w = w;
         *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
@@ -253,9 +307,14 @@ int gs_project_active(const float *points, const int32_t *counts, int B, int Nma
     hipStream_t st = (hipStream_t)stream;
     Cam *cams = (Cam *)ws;
     void *cws = (char *)ws + align_up(sizeof(Cam) * (size_t)B, 256);
+    const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
+    if (B <= kCamB) {  // cameras built per block in LDS: no preparation launch
+        ActivePredL pred{points, counts, poses, intrinsics, B, Nmax, H, W, ds, umax, vmax};
+        ActiveWriterL wr{points, out_rows, Nmax, H, W, umax, vmax};
+        return compact_launch((int64_t)B * Nmax, pred, wr, out_count, cws, st, "gs_project_active");
+    }
     hipLaunchKernelGGL(build_cams_k, dim3(cdiv(B, 64)), dim3(64), 0, st, poses, intrinsics, B, cams);
     GS_LAUNCH_CHECK("gs_project_active/cams");
-    const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
     ActivePred pred{points, counts, cams, Nmax, H, W, ds, umax, vmax};
     ActiveWriter wr{points, cams, out_rows, Nmax, H, W, umax, vmax};
     return compact_launch((int64_t)B * Nmax, pred, wr, out_count, cws, st, "gs_project_active");

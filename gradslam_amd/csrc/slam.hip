@@ -43,19 +43,19 @@ static bool graphs_allowed() {
     return on && !profiling_enabled();
 }
 
-// kornia.geometry.linalg.compose_transformations semantics (call site reference slam/icpslam.py:245-247):
-// R = R01 R12 ; t = R01 t12 + t01 ; bottom row [0,0,0,1].   out[b] = T[b] . P[b]
+// out[b] = T[b] . P[b]   (compose44, gs_common.hpp)
 __global__ void compose_k(const float *__restrict__ T, const float *__restrict__ P, int B, float *__restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float *a = T + 16 * b, *p = P + 16 * b;
-    float *o = out + 16 * b;
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) o[4 * i + j] = dot3_fma(a[4 * i], a[4 * i + 1], a[4 * i + 2], p[j], p[4 + j], p[8 + j]);
-        o[4 * i + 3] = dot3_fma(a[4 * i], a[4 * i + 1], a[4 * i + 2], p[3], p[7], p[11]) + a[4 * i + 3];
-    }
-    o[12] = 0.0f; o[13] = 0.0f; o[14] = 0.0f; o[15] = 1.0f;
+    compose44(T + 16 * b, P + 16 * b, out + 16 * b);
 }
+
+// icp.hip: gs_icp_point_to_plane[_grad|_taped] with the pose composition folded into the loop's last launch
+// (compose_out = out_T . compose_right; both optional)
+int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
+                     const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
+                     float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out);
 
 __global__ void eye4_k(float *__restrict__ T, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,20 +288,19 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     // per ds-grid pixel (search hints only)
     if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
                                   w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.sub, w.sub_bytes, stream))) return rc;
-    auto enqueue_loops = [&](gs_stream_t s) -> int {
+    // fold_compose: the loop's last launch also writes out_poses = T . prev_poses.  Only for eager launches: a
+    // captured graph must not bake the caller's prev_poses / out_poses addresses in (they change every call).
+    auto enqueue_loops = [&](gs_stream_t s, bool fold_compose) -> int {
         for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
             const float *src = w.src + (size_t)b * capS * 3;
             const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
             const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
                                      w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
-            int r;
-            if (use_grad_lm)
-                r = gs_icp_point_to_plane_grad(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, nullptr /* identity */, numiters, damp,
-                                               dist_thresh, lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, nullptr, nullptr, w.sub,
-                                               w.sub_bytes, s);
-            else
-                r = gs_icp_point_to_plane(src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, nullptr /* identity */, numiters, damp,
-                                          dist_thresh, &hints, w.T + 16 * b, nullptr, nullptr, w.sub, w.sub_bytes, s);
+            // the loop's last launch also writes out_poses[b] = T . prev_poses[b]
+            const int r = icp_localize_run(use_grad_lm, src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, numiters, damp, dist_thresh,
+                                           lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)s, nullptr,
+                                           0, fold_compose ? prev_poses + 16 * b : nullptr,
+                                           fold_compose ? out_poses + 16 * b : nullptr);
             if (r) return r;
         }
         return GS_OK;
@@ -330,7 +329,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
             bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
-                const int r = enqueue_loops((gs_stream_t)cs);
+                const int r = enqueue_loops((gs_stream_t)cs, false);
                 const hipError_t e = hipStreamEndCapture(cs, &graph);
                 ok = (r == GS_OK) && e == hipSuccess && graph != nullptr;
             }
@@ -357,7 +356,10 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
             launched = true;
         }
     }
-    if (!launched && (rc = enqueue_loops(stream))) return rc;
+    if (!launched) {
+        if ((rc = enqueue_loops(stream, numiters > 0))) return rc;
+        if (numiters > 0) return GS_OK;  // composed by the loop's last launch
+    }
     return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);
 }
 
@@ -448,13 +450,14 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
     for (int b = 0; b < B; ++b) {
         const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, tp.src_pix + (size_t)b * capS,
                                  w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
-        if ((rc = gs_icp_point_to_plane_taped(tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
-                                              w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, nullptr /* identity */, numiters, damp,
-                                              dist_thresh, use_grad_lm, lambda_max, Bp, B2, nu, &hints, tp.T + 16 * b, nullptr,
-                                              tp.icp + (size_t)b * tp.icp_bytes, tp.icp_bytes, w.sub, w.sub_bytes, stream)))
+        if ((rc = icp_localize_run(use_grad_lm, tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
+                                   w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, numiters, damp, dist_thresh, lambda_max, Bp, B2, nu,
+                                   &hints, tp.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)stream, tp.icp + (size_t)b * tp.icp_bytes,
+                                   tp.icp_bytes, prev_poses + 16 * b, out_poses + 16 * b)))
             return rc;
     }
-    return gs_compose_poses(tp.T, prev_poses, B, out_poses, stream);
+    if (numiters == 0) return gs_compose_poses(tp.T, prev_poses, B, out_poses, stream);
+    return GS_OK;
 }
 
 size_t gs_slam_localize_backward_ws_bytes(int B, int H, int W, int ds, int Nmax) {
