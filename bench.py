@@ -225,8 +225,8 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         # per-kernel durations: a second, short pass of the same steps with HIP events recorded around the
-        # hot kernel on its launch stream (events force eager launches: the timed region above replays the ICP
-        # loop as a hipGraph, which is how the path is meant to run)
+        # hot kernel on its launch stream (events force eager launches; the timed region above runs in the
+        # library's automatic mode: eager launches on a fast host, hipGraph replay of the loop on a slow one)
         n_prof = min(args.steps, 20)
         nv.lib().gs_profile_enable(1)
         for i in range(n_prof):

@@ -1,6 +1,7 @@
 // slam.hip -- whole-step drivers: chains of the kernels of this library with every data-dependent size
 // kept on the device, so one C call enqueues a complete ICPSLAM._localize (reference
 // slam/icpslam.py:238-247) without a single host round trip.
+#include <chrono>
 #include <mutex>
 #include <stdlib.h>
 #include <vector>
@@ -36,11 +37,23 @@ static std::mutex g_graph_mu;
 static std::vector<GraphEntry> g_graphs;
 static std::vector<GraphKey> g_seen_once;  // a configuration is captured the second time it shows up
 static unsigned long long g_graph_clock = 0;
-static int g_graph_mode = -1;  // -1: from the environment, 0: off, 1: on
+static int g_graph_mode = -1;  // -1: automatic, 0: off, 1: on
+// Automatic mode.  With the step folded into the association a loop is 13 launches, and on a fast host
+// launching them eagerly is as fast as replaying a graph (and lets the loop's last launch write the composed
+// pose); on a slow host the ~2x lower host cost of a replay is what keeps the step GPU-bound.  So the library
+// times its own eager enqueues (host clock around the loop's launches, minimum over the first calls -- the
+// minimum, because a full queue makes a launch block) and turns graphs on only if a launch costs the host
+// more than kSlowLaunchUs.  GS_NO_GRAPH=1 / GS_GRAPH=1 in the environment, or gs_set_graph_mode, override.
+constexpr double kSlowLaunchUs = 5.0;
+static int g_auto_samples = 0;
+static double g_auto_min_us = 1e30;
 static bool graphs_allowed() {
-    static const bool env_off = getenv("GS_NO_GRAPH") != nullptr;
-    const bool on = (g_graph_mode < 0) ? !env_off : (g_graph_mode != 0);
-    return on && !profiling_enabled();
+    static const bool env_off = getenv("GS_NO_GRAPH") != nullptr, env_on = getenv("GS_GRAPH") != nullptr;
+    if (profiling_enabled()) return false;
+    if (g_graph_mode >= 0) return g_graph_mode != 0;
+    if (env_off) return false;
+    if (env_on) return true;
+    return g_auto_samples >= 4 && g_auto_min_us > kSlowLaunchUs;
 }
 
 // out[b] = T[b] . P[b]   (compose44, gs_common.hpp)
@@ -357,8 +370,18 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
         }
     }
     if (!launched) {
+        const auto t0 = std::chrono::steady_clock::now();
         if ((rc = enqueue_loops(stream, numiters > 0))) return rc;
-        if (numiters > 0) return GS_OK;  // composed by the loop's last launch
+        if (numiters > 0) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            const int launches = B * ((use_grad_lm ? 2 * numiters : numiters + 1) + 2);
+            std::lock_guard<std::mutex> lock(g_graph_mu);
+            if (g_auto_samples < 64) {
+                ++g_auto_samples;
+                g_auto_min_us = std::min(g_auto_min_us, us / launches);
+            }
+            return GS_OK;  // composed by the loop's last launch
+        }
     }
     return gs_compose_poses(w.T, prev_poses, B, out_poses, stream);
 }

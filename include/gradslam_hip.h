@@ -319,9 +319,10 @@ int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int 
  * element; prev_poses / out_poses are B x 16.  vertex / normal / gnormal (B,H,W,3) are optional outputs
  * (NULL to skip), gvertex is required scratch/output.  use_grad_lm selects the gradLM variant. */
 int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream);
-/* gs_slam_localize replays its ICP loops as a cached hipGraph once a configuration repeats (all loop
- * arguments live in the caller's workspace).  mode: 1 on, 0 off (eager launches), -1 default (on unless the
- * environment variable GS_NO_GRAPH is set).  Results are identical either way. */
+/* gs_slam_localize can replay its ICP loops as a cached hipGraph once a configuration repeats (all loop
+ * arguments live in the caller's workspace).  mode: 1 on, 0 off (eager launches), -1 automatic: the library
+ * times its own eager launches on the host and switches to graph replay only on hosts where a launch costs
+ * more than ~5 us (environment: GS_NO_GRAPH=1 / GS_GRAPH=1 force either).  Results are identical either way. */
 void gs_set_graph_mode(int mode);
 size_t gs_slam_localize_ws_bytes(int B, int H, int W, int ds, int Nmax);
 int gs_slam_localize(const float *depth, const float *intrinsics, const float *prev_poses, int B,
