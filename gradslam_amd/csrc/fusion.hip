@@ -92,6 +92,32 @@ struct PixWriter {
     }
 };
 
+// PixWriter that also records, per matched map point, the pixel it matched (what scatter_match_k builds for the
+// merge): the arena driver's fused form
+struct PixWriterM {
+    const unsigned int *pix_n;
+    int64_t *rows;
+    int *match;  // (B*Nmax), pre-filled with -1
+    int H, W, Nmax;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int64_t hw = (int64_t)H * W;
+        const int b = (int)(i / hw);
+        const int rem = (int)(i - (int64_t)b * hw);
+        const unsigned int n = pix_n[i];
+        longlong4 r;
+        r.x = b; r.y = n; r.z = rem / W; r.w = rem % W;
+        *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
+        match[(int64_t)b * Nmax + n] = rem;
+    }
+};
+// fuse_with_map's append mask (slam/fusionutils.py:702-707) straight from the unique stage's per-pixel winner:
+// valid depth and no correspondence at that pixel
+struct AppendPredPix {
+    const float *depth;
+    const unsigned int *pix_n;
+    __device__ bool operator()(int64_t i) const { return depth[i] > 0.0f && pix_n[i] == 0xffffffffu; }
+};
+
 // ------------------------------------------------------------------ F
 __global__ void fill_i32_k(int *__restrict__ p, int64_t n, int v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -329,6 +355,74 @@ int gs_fusion_merge(const int64_t *rows, const int32_t *d_n_rows, int64_t max_ro
     GS_LAUNCH_CHECK("gs_fusion_merge");
     return GS_OK;
 }
+
+}  // extern "C"
+
+namespace gs {
+// ---- fused forms used by gs_pointfusion_update (slam.hip): same kernels, fewer launches.
+// state = [pix_key (npix x 8) | pix_n (npix x 4) | match (B*Nmax x 4)], all initialised by ONE memset (0xff:
+// "no candidate" for the keys, "no winner" for pix_n, -1 for match); pix_n and match stay valid for the
+// merge and the append that follow.
+size_t fusion_state_bytes(int B, int H, int W, int Nmax) {
+    const size_t npix = (size_t)B * H * W;
+    return align_up(npix * 8, 256) + align_up(npix * 4, 256) + align_up((size_t)B * Nmax * 4, 256);
+}
+static inline void fusion_state_ptrs(void *state, int B, int H, int W, unsigned long long **key, unsigned int **pix_n, int **match) {
+    const size_t npix = (size_t)B * H * W;
+    *key = (unsigned long long *)state;
+    *pix_n = (unsigned int *)((char *)state + align_up(npix * 8, 256));
+    *match = (int *)((char *)*pix_n + align_up(npix * 4, 256));
+}
+int fusion_unique_match(const int64_t *rows, const uint8_t *keep, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
+                        int B, int H, int W, const float *map_points, const float *map_ccounts, int Nmax, int64_t *out_rows,
+                        int32_t *out_count, void *state, void *cws, hipStream_t st) {
+    unsigned long long *pix_key; unsigned int *pix_n; int *match;
+    fusion_state_ptrs(state, B, H, W, &pix_key, &pix_n, &match);
+    GS_HIP(hipMemsetAsync(state, 0xff, fusion_state_bytes(B, H, W, Nmax), st), "gs_pointfusion_update/unique memset");
+    if (max_rows > 0) {
+        hipLaunchKernelGGL(unique_pass1_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, keep, d_n_rows, gvertex, H, W, map_points,
+                           map_ccounts, Nmax, pix_key);
+        hipLaunchKernelGGL(unique_pass2_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, keep, d_n_rows, gvertex, H, W, map_points,
+                           map_ccounts, Nmax, pix_key, pix_n);
+        GS_LAUNCH_CHECK("gs_pointfusion_update/unique");
+    }
+    PixPred pred{pix_n};
+    PixWriterM wr{pix_n, out_rows, match, H, W, Nmax};
+    return compact_launch((int64_t)B * H * W, pred, wr, out_count, cws, st, "gs_pointfusion_update/unique compact");
+}
+int fusion_merge_prebuilt(const void *state, const int32_t *d_n_rows, const float *gvertex, const float *gnormal, const float *rgb,
+                          const float *alpha, int B, int H, int W, int Nmax, const int32_t *counts, float *points, float *normals,
+                          float *colors, float *ccounts, hipStream_t st) {
+    unsigned long long *pix_key; unsigned int *pix_n; int *match;
+    fusion_state_ptrs((void *)state, B, H, W, &pix_key, &pix_n, &match);
+    hipLaunchKernelGGL(merge_inplace_k, dim3(grid1d(Nmax), B), dim3(256), 0, st, (const int *)match, counts, d_n_rows, Nmax, H * W,
+                       gvertex, gnormal, rgb, alpha, points, normals, colors, ccounts);
+    GS_LAUNCH_CHECK("gs_pointfusion_update/merge");
+    return GS_OK;
+}
+// unmatched valid pixels of batch element b appended behind the rows its arena already holds
+int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const float *depth, const float *const *h_src,
+                            const int *h_row_floats, float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended,
+                            int32_t *d_overflow, void *cws, hipStream_t st) {
+    unsigned long long *pix_key; unsigned int *pix_n; int *match;
+    fusion_state_ptrs((void *)state, B, H, W, &pix_key, &pix_n, &match);
+    const int64_t HW = (int64_t)H * W;
+    AppendWriter wr;
+    wr.n_arrays = 4; wr.base = d_count; wr.cap = cap;
+    for (int a = 0; a < 4; ++a) {
+        wr.src[a] = (const uint32_t *)h_src[a]; wr.out[a] = (uint32_t *)h_dst[a]; wr.words[a] = h_row_floats[a];
+    }
+    int *total = (int *)((char *)cws + compact_ws_bytes(HW));
+    AppendPredPix pred{depth + b * HW, pix_n + b * HW};
+    const int rc = compact_launch(HW, pred, wr, total, cws, st, "gs_pointfusion_update/append");
+    if (rc) return rc;
+    hipLaunchKernelGGL(append_count_k, dim3(1), dim3(64), 0, st, d_count, total, cap, d_appended, d_overflow);
+    GS_LAUNCH_CHECK("gs_pointfusion_update/append count");
+    return GS_OK;
+}
+}  // namespace gs
+
+extern "C" {
 
 size_t gs_fusion_merge_inplace_ws_bytes(int B, int Nmax) { return gs_fusion_merge_ws_bytes(B, Nmax); }
 

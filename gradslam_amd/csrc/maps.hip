@@ -435,39 +435,6 @@ __global__ void frames_from_raw_k(const uint16_t *__restrict__ depth_raw, const 
     }
 }
 
-// MultiWriter that appends: selected rows go behind the *base rows a destination already holds (device-side
-// count), rows that would not fit into `cap` are dropped (the caller sizes cap so that this never happens and
-// checks the overflow flag)
-struct AppendWriter {
-    const uint32_t *src[4];
-    uint32_t *out[4];
-    int words[4];
-    int n_arrays;
-    const int32_t *base;
-    int cap;
-    __device__ void operator()(int64_t i, int64_t pos) const {
-        const int64_t at = (int64_t)(*base) + pos;
-        if (at >= cap) return;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            if (a >= n_arrays) break;
-            const int w = words[a];
-            for (int k = 0; k < w; ++k) out[a][at * w + k] = src[a][i * w + k];
-        }
-    }
-};
-
-__global__ void append_count_k(int32_t *__restrict__ count, const int *__restrict__ total, int cap,
-                               int32_t *__restrict__ appended, int32_t *__restrict__ overflow) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int64_t want = (int64_t)*count + *total;
-        const int now = (int)(want > cap ? cap : want);
-        if (appended) *appended = now - *count;
-        if (overflow && want > cap) *overflow = 1;
-        *count = now;
-    }
-}
-
 // adjoint of MultiWriter: row i of every output = the compacted row it went to, or zero
 struct ExpandWriter {
     const uint32_t *g[4];

@@ -131,12 +131,26 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     return off;
 }
 
+// fusion.hip: fused forms of the unique / merge / append stages (one memset instead of two memsets + a fill, the
+// match table written by the unique stage's compaction, the append mask read from its per-pixel winners)
+size_t fusion_state_bytes(int B, int H, int W, int Nmax);
+int fusion_unique_match(const int64_t *rows, const uint8_t *keep, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
+                        int B, int H, int W, const float *map_points, const float *map_ccounts, int Nmax, int64_t *out_rows,
+                        int32_t *out_count, void *state, void *cws, hipStream_t st);
+int fusion_merge_prebuilt(const void *state, const int32_t *d_n_rows, const float *gvertex, const float *gnormal, const float *rgb,
+                          const float *alpha, int B, int H, int W, int Nmax, const int32_t *counts, float *points, float *normals,
+                          float *colors, float *ccounts, hipStream_t st);
+int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const float *depth, const float *const *h_src,
+                            const int *h_row_floats, float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended,
+                            int32_t *d_overflow, void *cws, hipStream_t st);
+
 // ------------------------------------------------------------------ PointFusion map update on an arena
 struct FuseWs {
     float *V, *N, *gV, *gN, *alpha;  // (B,H,W,3) x4, (B,H,W)
     int64_t *rows;                   // (B*Nmax, 4) active rows
     int64_t *urows;                  // (B*H*W, 4) unique rows
-    uint8_t *keep, *mask;            // (B*Nmax), (B*H*W)
+    uint8_t *keep;                   // (B*Nmax)
+    void *state;                     // unique stage: per-pixel keys / winners + per-point match table
     int32_t *nrows, *ucnt, *appended, *overflow;  // (1),(1),(B),(1)
     float *max_dot;                  // (1)
     void *sub;
@@ -147,18 +161,16 @@ static size_t fuse_layout(int B, int H, int W, int Nmax, void *ws, FuseWs *out) 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t oV = take(npix * 12), oN = take(npix * 12), ogV = take(npix * 12), ogN = take(npix * 12), oA = take(npix * 4);
-    const size_t oR = take(npt * 32), oU = take(npix * 32), oK = take(npt), oM = take(npix);
+    const size_t oR = take(npt * 32), oU = take(npix * 32), oK = take(npt), oM = take(fusion_state_bytes(B, H, W, Nmax));
     const size_t oC = take(256 + (size_t)B * 4);
     size_t sub = gs_project_active_ws_bytes(B, Nmax);
-    sub = std::max(sub, gs_fusion_unique_ws_bytes(B, H, W));
-    sub = std::max(sub, gs_fusion_merge_inplace_ws_bytes(B, Nmax));
-    sub = std::max(sub, gs_append_rows_ws_bytes((int64_t)H * W));
+    sub = std::max(sub, gs_compact_ws_bytes((int64_t)B * H * W) + 256);
     const size_t oS = take(sub);
     if (ws && out) {
         char *p = (char *)ws;
         out->V = (float *)(p + oV); out->N = (float *)(p + oN); out->gV = (float *)(p + ogV); out->gN = (float *)(p + ogN);
         out->alpha = (float *)(p + oA); out->rows = (int64_t *)(p + oR); out->urows = (int64_t *)(p + oU);
-        out->keep = (uint8_t *)(p + oK); out->mask = (uint8_t *)(p + oM);
+        out->keep = (uint8_t *)(p + oK); out->state = p + oM;
         int32_t *c = (int32_t *)(p + oC);
         out->nrows = c; out->ucnt = c + 1; out->overflow = c + 2; out->max_dot = (float *)(c + 3); out->appended = c + 64;
         out->sub = p + oS; out->sub_bytes = sub;
@@ -417,20 +429,19 @@ int gs_pointfusion_update(const float *depth, const float *rgb, const float *int
                                 stream))) return rc;
     if ((rc = gs_fusion_similar(w.rows, w.nrows, npt, w.gV, w.gN, H, W, map_points, map_normals, Nmax, dist_th, dot_th, w.keep,
                                 w.max_dot, stream))) return rc;
-    if ((rc = gs_fusion_unique(w.rows, w.keep, w.nrows, npt, w.gV, B, H, W, map_points, map_ccounts, Nmax, w.urows, w.ucnt, w.sub,
-                               w.sub_bytes, stream))) return rc;
+    if ((rc = fusion_unique_match(w.rows, w.keep, w.nrows, npt, w.gV, B, H, W, map_points, map_ccounts, Nmax, w.urows, w.ucnt, w.state,
+                                  w.sub, st))) return rc;
     // fuse_with_map (fusionutils.py:654-720): merge in place, then append the unmatched valid pixels
-    if ((rc = gs_fusion_merge_inplace(w.urows, w.ucnt, npix, w.gV, w.gN, rgb, w.alpha, B, H, W, Nmax, map_counts, map_points,
-                                      map_normals, map_colors, map_ccounts, w.sub, w.sub_bytes, stream))) return rc;
-    if ((rc = gs_fusion_new_mask(depth, w.urows, w.ucnt, npix, B, H, W, w.mask, stream))) return rc;
+    if ((rc = fusion_merge_prebuilt(w.state, w.ucnt, w.gV, w.gN, rgb, w.alpha, B, H, W, Nmax, map_counts, map_points, map_normals,
+                                    map_colors, map_ccounts, st))) return rc;
     const int64_t HW = (int64_t)H * W;
     for (int b = 0; b < B; ++b) {
         const float *src[4] = {w.gV + b * HW * 3, w.gN + b * HW * 3, rgb + b * HW * 3, w.alpha + b * HW};
         float *dst[4] = {map_points + (size_t)b * Nmax * 3, map_normals + (size_t)b * Nmax * 3, map_colors + (size_t)b * Nmax * 3,
                          map_ccounts + (size_t)b * Nmax};
         const int widths[4] = {3, 3, 3, 1};
-        if ((rc = gs_append_rows(4, src, widths, dst, w.mask + b * HW, HW, map_counts + b, Nmax, w.appended + b, w.overflow, w.sub,
-                                 w.sub_bytes, stream))) return rc;
+        if ((rc = fusion_append_unmatched(w.state, B, H, W, b, depth, src, widths, dst, map_counts + b, Nmax, w.appended + b,
+                                          w.overflow, w.sub, st))) return rc;
     }
     if (stats) {
         hipLaunchKernelGGL(fuse_stats_k, dim3(1), dim3(64), 0, st, w.nrows, w.ucnt, w.overflow, w.max_dot, w.appended, B, stats);
