@@ -43,10 +43,13 @@ static int g_graph_mode = -1;  // -1: automatic, 0: off, 1: on
 // pose); on a slow host the ~2x lower host cost of a replay is what keeps the step GPU-bound.  So the library
 // times its own eager enqueues (host clock around the loop's launches, minimum over the first calls -- the
 // minimum, because a full queue makes a launch block) and turns graphs on only if a launch costs the host
-// more than kSlowLaunchUs.  GS_NO_GRAPH=1 / GS_GRAPH=1 in the environment, or gs_set_graph_mode, override.
-constexpr double kSlowLaunchUs = 5.0;
+// more than kSlowLaunchUs -- about where the ~24 launches of a step would take the host as long as they take
+// the GPU (a fast host needs ~3 us per launch).  Capturing costs several milliseconds once, so a borderline
+// host is better off eager.  GS_NO_GRAPH=1 / GS_GRAPH=1 in the environment, or gs_set_graph_mode, override.
+constexpr double kSlowLaunchUs = 8.0;
 static int g_auto_samples = 0;
 static double g_auto_min_us = 1e30;
+static int g_captures = 0, g_replays = 0;
 static bool graphs_allowed() {
     static const bool env_off = getenv("GS_NO_GRAPH") != nullptr, env_on = getenv("GS_GRAPH") != nullptr;
     if (profiling_enabled()) return false;
@@ -273,6 +276,13 @@ extern "C" {
 
 void gs_set_graph_mode(int mode) { g_graph_mode = mode; }
 
+int gs_graph_stats(double *out4) {
+    GS_REQUIRE(out4, "gs_graph_stats: NULL argument");
+    std::lock_guard<std::mutex> lock(g_graph_mu);
+    out4[0] = g_auto_samples; out4[1] = g_auto_min_us; out4[2] = g_captures; out4[3] = g_replays;
+    return GS_OK;
+}
+
 int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream) {
     GS_REQUIRE(T && P && out && B > 0, "gs_compose_poses: bad arguments");
     hipLaunchKernelGGL(compose_k, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, T, P, B, out);
@@ -371,12 +381,14 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
                 }
                 g_graphs.push_back(GraphEntry{key, device, exec, 0});
                 hit = &g_graphs.back();
+                ++g_captures;
             } else {
                 (void)hipGetLastError();  // fall back to eager launches below
             }
         }
         if (hit) {
             hit->last_use = ++g_graph_clock;
+            ++g_replays;
             GS_HIP(hipGraphLaunch(hit->exec, st), "gs_slam_localize/graph");
             launched = true;
         }

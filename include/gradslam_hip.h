@@ -322,8 +322,11 @@ int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_strea
 /* gs_slam_localize can replay its ICP loops as a cached hipGraph once a configuration repeats (all loop
  * arguments live in the caller's workspace).  mode: 1 on, 0 off (eager launches), -1 automatic: the library
  * times its own eager launches on the host and switches to graph replay only on hosts where a launch costs
- * more than ~5 us (environment: GS_NO_GRAPH=1 / GS_GRAPH=1 force either).  Results are identical either way. */
+ * more than ~8 us (environment: GS_NO_GRAPH=1 / GS_GRAPH=1 force either).  Results are identical either way. */
 void gs_set_graph_mode(int mode);
+/* Diagnostics of that policy: out4 = {eager enqueues timed, their minimum host cost per launch in us, graphs
+ * captured, graph replays}. */
+int gs_graph_stats(double *out4);
 size_t gs_slam_localize_ws_bytes(int B, int H, int W, int ds, int Nmax);
 int gs_slam_localize(const float *depth, const float *intrinsics, const float *prev_poses, int B,
                      int H, int W, int ds, const float *map_points, const float *map_normals,
