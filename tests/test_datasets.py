@@ -243,3 +243,61 @@ def test_helpers_against_reference_golden(golden, tmp_path):
     tr = tumutils.read_trajectory(ft, matrix=True)
     np.testing.assert_array_equal([float(k) for k in tr.keys()], g["traj_keys"])
     np.testing.assert_array_equal(np.stack(list(tr.values())), g["traj_T"])
+
+
+# ---------------------------------------------------------------------- ICL on a synthetic tree
+@pytest.fixture(scope="module")
+def icl_tree(tmp_path_factory):
+    from PIL import Image
+
+    root = tmp_path_factory.mktemp("ICL")
+    rng = np.random.default_rng(5)
+    truth = {}
+    for traj, n in ((0, 7), (2, 6)):
+        tdir = root / ("living_room_traj%d_frei_png" % traj)
+        (tdir / "rgb").mkdir(parents=True)
+        (tdir / "depth").mkdir()
+        assoc, sim = [], []
+        truth[traj] = {"rgb": [], "depth": [], "pose": []}
+        for i in range(n):
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            depth = rng.integers(1, 40000, (H, W), dtype=np.uint16)
+            Image.fromarray(rgb, "RGB").save(tdir / "rgb" / ("%d.png" % i))
+            Image.fromarray(depth).save(tdir / "depth" / ("%d.png" % i))
+            assoc.append("%d depth/%d.png %d rgb/%d.png" % (i, i, i, i))
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = _rot([0.3, -1.0, 0.2], 0.03 * i + 0.2), [0.1 * i, 0.02 * i, -0.05 * i]
+            truth[traj]["rgb"].append(rgb); truth[traj]["depth"].append(depth); truth[traj]["pose"].append(T)
+            if not (traj == 0 and i == n - 1):  # traj0's pose file is one pose short, like the real one
+                sim += [" ".join("%.8f" % v for v in T[r]) for r in range(3)] + [""]
+        (tdir / "associations.txt").write_text("\n".join(assoc) + "\n")
+        (tdir / ("livingRoom%dn.gt.sim" % traj)).write_text("\n".join(sim) + "\n")
+    return str(root), truth
+
+
+def test_icl_sequences_and_values(icl_tree):
+    from gradslam_amd.datasets import ICL
+
+    root, truth = icl_tree
+    ds = ICL(root, seqlen=3, stride=3, height=H, width=W)
+    # traj0: 7 frames minus the dropped last one = 6 -> 2 sequences; traj2: 6 -> 2 sequences
+    assert len(ds) == 4
+    color, depth, K, poses, transforms, names = ds[3]      # traj2, frames 3,4,5
+    assert color.shape == (3, H, W, 3) and depth.shape == (3, H, W, 1) and names.count(",") == 2
+    for j, f in enumerate((3, 4, 5)):
+        assert torch.equal(color[j], torch.from_numpy(truth[2]["rgb"][f]).float())
+        assert torch.equal(depth[j, ..., 0], torch.from_numpy(truth[2]["depth"][f].astype(np.int64) / 5000.0).float())
+    np.testing.assert_allclose(K[0].numpy(), [[481.2 * W / 640, 0, 319.5 * W / 640, 0], [0, -480.0 * H / 480, 239.5 * H / 480, 0],
+                                              [0, 0, 1, 0], [0, 0, 0, 1]], rtol=1e-6)
+    P = [truth[2]["pose"][f] for f in (3, 4, 5)]
+    np.testing.assert_allclose(poses[0].numpy(), np.eye(4), atol=1e-5)
+    np.testing.assert_allclose(poses[2].numpy(), np.linalg.inv(P[0]) @ P[2], atol=2e-5)
+    np.testing.assert_allclose(transforms[1].numpy(), np.linalg.inv(P[0]) @ P[1], atol=2e-5)
+    assert len(ICL(root, trajectories=("living_room_traj2_frei_png",), seqlen=2, start=1, end=5, return_pose=False,
+                   return_transform=False)) == 2
+    with pytest.raises(ValueError):
+        ICL(root, trajectories=("living_room_traj7_frei_png",))
+    with pytest.raises(ValueError):
+        ICL(root, trajectories=("not_a_trajectory",))
+    with pytest.raises(TypeError):
+        ICL(root, trajectories=["living_room_traj2_frei_png"])
