@@ -491,5 +491,34 @@ class Pointclouds(object):
     def open3d(self, *args, **kwargs):
         raise NotImplementedError("open3d export is outside the accelerated hot path (SURVEY.md section 8f-4)")
 
-    def plotly(self, *args, **kwargs):
-        raise NotImplementedError("plotly export is outside the accelerated hot path (SURVEY.md section 8f-4)")
+    def plotly(self, index: int, include_colors: bool = True, max_num_points: Optional[int] = 200000, as_figure: bool = True,
+               point_size: int = 2):
+        """`index`-th cloud as a `plotly.graph_objects.Figure` (or `Scatter3d` if not `as_figure`) for viewing
+        (reference :1296-1383): a device-to-host copy of at most `max_num_points` randomly chosen points; colours
+        in [0, 1.1) are taken to be normalised and scaled to 0..255."""
+        import plotly.graph_objects as go
+
+        if not isinstance(index, int):
+            raise TypeError("Index should be int, but was {}.".format(type(index)))
+        points = self.points_list[index]
+        n = points.shape[0]
+        subsample = max_num_points is not None and max_num_points < n
+        if subsample:
+            keep = torch.randperm(n)[:max_num_points].to(points.device)
+            points = points[keep]
+        xyz = points.detach().cpu().numpy()
+        marker = {"size": point_size}
+        if self.has_colors and include_colors:
+            colors = self.colors_list[index]
+            if subsample:
+                colors = colors[keep]
+            if (colors.max() < 1.1).item():
+                colors = colors * 255
+            marker["color"] = torch.clamp(colors, min=0.0, max=255.0).detach().cpu().numpy().astype("uint8")
+        scatter = go.Scatter3d(x=xyz[..., 0], y=xyz[..., 1], z=xyz[..., 2], mode="markers", marker=marker)
+        if not as_figure:
+            return scatter
+        hidden = dict(showticklabels=False, showgrid=False, zeroline=False, visible=False)
+        fig = go.Figure(data=[scatter])
+        fig.update_layout(showlegend=False, scene=dict(xaxis=hidden, yaxis=hidden, zaxis=hidden))
+        return fig

@@ -289,3 +289,19 @@ def test_se3_and_rigid_algebra():
     assert torch.allclose(small[:3, 3], torch.tensor([1.0, 2.0, 3.0]), atol=1e-6)
     g = gu.create_meshgrid(3, 4, normalized_coords=False)
     assert g.shape == (1, 3, 4, 2) and g[0, 2, 3].tolist() == [2.0, 3.0]
+
+
+def test_pointclouds_plotly_export():
+    """Viewer export (reference structures/pointclouds.py:1296-1383): host-side, works on any device."""
+    import gradslam_amd as gs
+
+    torch.manual_seed(0)
+    pts, cols = torch.rand(2, 50, 3), torch.rand(2, 50, 3)
+    pc = gs.Pointclouds(points=pts, colors=cols)
+    sc = pc.plotly(1, as_figure=False)
+    assert len(sc.x) == 50 and abs(float(sc.z[7]) - float(pts[1, 7, 2])) < 1e-7
+    assert sc.marker.color.shape == (50, 3) and sc.marker.color.dtype.name == "uint8" and int(sc.marker.color.max()) > 200
+    fig = pc.plotly(0, max_num_points=10)
+    assert len(fig.data) == 1 and len(fig.data[0].x) == 10
+    with pytest.raises(TypeError):
+        pc.plotly("0")
