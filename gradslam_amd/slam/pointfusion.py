@@ -133,7 +133,7 @@ class PointFusion(ICPSLAM):
         stats = torch.zeros((L, 4 + B), dtype=torch.int32, device=dev)
         p = self.odomprov
         gparams = (p.lambda_max, p.B, p.B2, p.nu) if self.odom == "gradicp" else None
-        frame = lambda x, s: x[:, s] if B == 1 else x[:, s].contiguous()  # (B,H,W,C) contiguous
+        frame = lambda x, s: x[:, s].contiguous()  # (B,H,W,C); a view (no copy) for one contiguous sequence
         prev = None
         for s in range(L):  # true serial dependence: pose s needs map s-1
             d_s, c_s = frame(depth, s), frame(rgb, s)
