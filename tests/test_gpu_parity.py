@@ -695,3 +695,28 @@ def test_streamed_arena_forward_equals_stepwise(gs, odom, B):
             assert torch.equal(getattr(pa, attr)[b], getattr(pb, attr)[b]), (attr, b)
     # padded views keep the zero-padding contract
     assert torch.equal(pa.points_padded, pb.points_padded)
+
+
+@pytest.mark.parametrize("grad_lm", [False, True], ids=["LM", "gradLM"])
+def test_short_loops_match_the_per_op_formulation(gs, golden, grad_lm):
+    """numiters = 0, 1, 2, 3: the edge cases of the folded-step launch sequence (first association without a step,
+    the loop's last step as a launch of its own) against the per-op formulation of the same kernels."""
+    g = golden("ref_icp_grads")
+    ut = gs.odometry.icputils
+    fn = ut.point_to_plane_gradICP if grad_lm else ut.point_to_plane_ICP
+    s, tg, n, T0 = (d(g[k]) for k in ("src", "tgt", "tgt_n", "T0"))
+    for numiters in (0, 1, 2, 3):
+        Ta, ia = fn(s[None], tg[None], n[None], T0, numiters=numiters)           # device loop
+        s2 = s.clone().requires_grad_(True)
+        old, ut.FUSED_AUTOGRAD = ut.FUSED_AUTOGRAD, False
+        try:
+            Tb, ib = fn(s2[None], tg[None], n[None], T0, numiters=numiters)      # unrolled, one node per op
+        finally:
+            ut.FUSED_AUTOGRAD = old
+        s3 = s.clone().requires_grad_(True)
+        Tc, ic = fn(s3[None], tg[None], n[None], T0, numiters=numiters)          # taped loop
+        assert rel_err(Ta.cpu(), Tb.detach().cpu()) < 1e-5 and torch.equal(Ta, Tc.detach()), numiters
+        if numiters == 0:
+            assert ia is None and ib is None and torch.equal(Ta, T0)
+        else:
+            assert torch.equal(ia, ib) and torch.equal(ia, ic), numiters
