@@ -301,3 +301,63 @@ def test_icl_sequences_and_values(icl_tree):
         ICL(root, trajectories=("not_a_trajectory",))
     with pytest.raises(TypeError):
         ICL(root, trajectories=["living_room_traj2_frei_png"])
+
+
+# ---------------------------------------------------------------------- ScanNet on a synthetic tree
+def test_scannet_sequences_labels_and_tables(tmp_path):
+    from PIL import Image
+
+    from gradslam_amd.datasets import Scannet
+    from gradslam_amd.datasets.scannet import get_color_encoding, nyu40_to_scannet20
+
+    rng = np.random.default_rng(9)
+    base, meta = tmp_path / "scans", tmp_path / "sequence_associations"
+    meta.mkdir()
+    truth = {}
+    for scene in ("scene0000_00", "scene0001_00"):
+        for sub in ("color", "depth", "pose", "label-filt", "intrinsic"):
+            (base / scene / sub).mkdir(parents=True)
+        Kd = np.array([[577.6, 0, 318.9, 0], [0, 578.7, 242.7, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        np.savetxt(base / scene / "intrinsic" / "intrinsic_depth.txt", Kd)
+        lines, truth[scene] = [], {"rgb": [], "depth": [], "pose": [], "label": []}
+        for i in range(5):
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            depth = rng.integers(0, 9000, (H, W), dtype=np.uint16)
+            label = rng.integers(0, 41, (H, W), dtype=np.uint8)
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = _rot([0.1, 0.9, 0.4], 0.04 * i + 0.3), [0.2 * i, -0.1 * i, 0.05 * i]
+            Image.fromarray(rgb, "RGB").save(base / scene / "color" / ("%d.png" % i))   # (real ScanNet: .jpg)
+            Image.fromarray(depth).save(base / scene / "depth" / ("%d.png" % i))
+            Image.fromarray(label).save(base / scene / "label-filt" / ("%d.png" % i))
+            np.savetxt(base / scene / "pose" / ("%d.txt" % i), T)
+            f = lambda sub, ext: "%s/%s/%d.%s" % (scene, sub, i, ext)
+            lines.append("color %s depth %s pose %s label-filt %s a b c d e f intrinsic_depth %s/intrinsic/intrinsic_depth.txt"
+                         % (f("color", "png"), f("depth", "png"), f("pose", "txt"), f("label-filt", "png"), scene))
+            for k, v in (("rgb", rgb), ("depth", depth), ("pose", T), ("label", label)):
+                truth[scene][k].append(v)
+        (meta / ("%s-seq_0.txt" % scene)).write_text("\n".join(lines) + "\n")
+    ds = Scannet(str(base), str(meta), scenes=("scene0001_00",), start=1, end=4, height=H, width=W)
+    assert len(ds) == 1
+    color, depth, K, poses, transforms, name, labels = ds[0]
+    t = truth["scene0001_00"]
+    assert name == "scene0001_00-seq_0" and color.shape == (3, H, W, 3) and labels.shape == (3, H, W, 1)
+    for j, f in enumerate((1, 2, 3)):
+        assert torch.equal(color[j], torch.from_numpy(t["rgb"][f]).float())
+        assert torch.equal(depth[j, ..., 0], torch.from_numpy(t["depth"][f].astype(np.int64) / 1000.0).float())
+        assert torch.equal(labels[j, ..., 0], torch.from_numpy(nyu40_to_scannet20(t["label"][f].copy())).float())
+    np.testing.assert_allclose(K[0].numpy(), [[577.6 * W / 640, 0, 318.9 * W / 640, 0], [0, 578.7 * H / 480, 242.7 * H / 480, 0],
+                                              [0, 0, 1, 0], [0, 0, 0, 1]], rtol=1e-6)
+    np.testing.assert_allclose(poses[2].numpy(), np.linalg.inv(t["pose"][1]) @ t["pose"][3], atol=2e-5)
+    np.testing.assert_allclose(transforms[2].numpy(), np.linalg.inv(t["pose"][2]) @ t["pose"][3], atol=2e-5)
+    assert len(Scannet(str(base), str(meta), None, return_labels=False, seg_classes="nyu40")) == 2
+    # class tables: 41 NYU40 classes, 21 benchmark classes (incl. unlabeled), shared colours
+    nyu, s20 = get_color_encoding("nyu40"), get_color_encoding("scannet20")
+    assert len(nyu) == 41 and len(s20) == 21 and all(nyu[k] == v for k, v in s20.items())
+    assert list(s20)[:4] == ["unlabeled", "wall", "floor", "cabinet"] and list(s20)[-1] == "otherfurniture"
+    lab = np.arange(41, dtype=np.uint8)
+    out = nyu40_to_scannet20(lab.copy())
+    assert out.max() == 20 and out[39] == 20 and out[13] == 0 and out[14] == 13 and out[12] == 12
+    with pytest.raises(ValueError):
+        Scannet(str(base), str(meta), None, start=3, end=2)
+    with pytest.raises(ValueError):
+        Scannet(str(base), str(meta), None, start=0, end=9)
