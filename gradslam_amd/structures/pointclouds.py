@@ -488,8 +488,29 @@ class Pointclouds(object):
         return self
 
     # ------------------------------------------------------------------ export (out of scope: viewers)
-    def open3d(self, *args, **kwargs):
-        raise NotImplementedError("open3d export is outside the accelerated hot path (SURVEY.md section 8f-4)")
+    def open3d(self, index: int, include_colors: bool = True, max_num_points: Optional[int] = None,
+               include_normals: bool = False):
+        """`index`-th cloud as an `open3d.geometry.PointCloud` (reference :1239-1294): a device-to-host copy;
+        colours above 1.1 are taken to be 0..255 and normalised.  Needs the `open3d` package (not in this image)."""
+        import open3d as o3d
+
+        if not isinstance(index, int):
+            raise TypeError("Index should be int, but was {}.".format(type(index)))
+        n = self.points_list[index].shape[0]
+        keep = None
+        if max_num_points is not None and max_num_points < n:
+            keep = torch.randperm(n)[:max_num_points].to(self.device)
+        take = lambda x: (x if keep is None else x[keep]).detach().cpu().numpy()
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(take(self.points_list[index]))
+        if self.has_colors and include_colors:
+            colors = self.colors_list[index]
+            if (colors.max() > 1.1).item():
+                colors = colors / 255
+            pcd.colors = o3d.utility.Vector3dVector(take(torch.clamp(colors, min=0.0, max=1.0)))
+        if self.has_normals and include_normals:
+            pcd.normals = o3d.utility.Vector3dVector(take(self.normals_list[index]))
+        return pcd
 
     def plotly(self, index: int, include_colors: bool = True, max_num_points: Optional[int] = 200000, as_figure: bool = True,
                point_size: int = 2):

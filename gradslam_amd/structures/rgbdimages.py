@@ -308,5 +308,54 @@ class RGBDImages(object):
         out = tensor.permute(*ordering)
         return out.contiguous() if contiguous else out
 
-    def plotly(self, *args, **kwargs):
-        raise NotImplementedError("plotly export is outside the accelerated hot path (SURVEY.md section 8f-4)")
+    def plotly(self, index: int, include_depth: bool = True, as_figure: bool = True, ms_per_frame: int = 50):
+        """`index`-th sequence as an animated plotly figure (play / stop buttons and a frame slider; RGB on top,
+        depth below), or as the list of frame dicts `go.Figure(frames=...)` takes (reference :764-900).  Host side:
+        one device-to-host copy of the images."""
+        from plotly.subplots import make_subplots
+
+        from .structutils import numpy_to_plotly_image
+
+        if not isinstance(index, int):
+            raise TypeError("Index should be int, but was {}.".format(type(index)))
+        src = self.to_channels_last() if self.channels_first else self
+        rgb = src.rgb_image[index]
+        if (rgb.max() < 1.1).item():
+            rgb = rgb * 255
+        rgb = torch.clamp(rgb, min=0.0, max=255.0).detach().cpu().numpy().astype("uint8")
+        rgb_images = [numpy_to_plotly_image(im, i) for i, im in enumerate(rgb)]
+        if include_depth:
+            depth = src.depth_image[index, ..., 0]
+            scale = 10 ** torch.log10(255.0 / depth.detach().max()).floor().item()
+            depth = (depth * scale).detach().cpu().numpy().astype("uint8")
+            depth_images = [numpy_to_plotly_image(im, i, True, scale) for i, im in enumerate(depth)]
+            frames = [{"name": i, "data": [a, b], "traces": [0, 1]} for i, (a, b) in enumerate(zip(rgb_images, depth_images))]
+        else:
+            frames = [{"data": [a], "name": i} for i, a in enumerate(rgb_images)]
+        if not as_figure:
+            return frames
+
+        def animate(duration):
+            return {"frame": {"duration": duration, "redraw": True}, "mode": "immediate", "fromcurrent": True,
+                    "transition": {"duration": duration, "easing": "linear"}}
+
+        slider = {"active": 0, "yanchor": "top", "xanchor": "left", "currentvalue": {"prefix": "Frame: "},
+                  "pad": {"b": 10, "t": 60}, "len": 0.9, "x": 0.1, "y": 0,
+                  "steps": [{"args": [[i], animate(0)], "label": i, "method": "animate"} for i in range(self._L)]}
+        buttons = {"buttons": [{"args": [None, animate(ms_per_frame)], "label": "&#9654;", "method": "animate"},
+                               {"args": [[None], animate(0)], "label": "&#9724;", "method": "animate"}],
+                   "direction": "left", "pad": {"r": 10, "t": 70}, "showactive": False, "type": "buttons", "x": 0.1,
+                   "xanchor": "right", "y": 0, "yanchor": "top"}
+        if include_depth:
+            fig = make_subplots(rows=2, cols=1, subplot_titles=("RGB", "Depth"), shared_xaxes=True, shared_yaxes=False,
+                                vertical_spacing=0.1)
+            fig.add_trace(frames[0]["data"][0], row=1, col=1)
+            fig.add_trace(frames[0]["data"][1], row=2, col=1)
+            fig.update_layout(scene=dict(aspectmode="data"))
+            fig.update_layout(autosize=False, height=1080)
+        else:
+            fig = make_subplots(rows=1, cols=1, subplot_titles=("RGB",))
+            fig.add_traces(frames[0]["data"][0])
+        fig.update(frames=frames)
+        fig.update_layout(updatemenus=[buttons], sliders=[slider])
+        return fig

@@ -4,7 +4,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-__all__ = ["list_to_padded", "padded_to_list"]
+__all__ = ["list_to_padded", "padded_to_list", "numpy_to_plotly_image", "img_to_b64str"]
 
 
 def list_to_padded(x: List[torch.Tensor], pad_size: Optional[Sequence[int]] = None, pad_value: float = 0.0,
@@ -47,3 +47,33 @@ def padded_to_list(x: torch.Tensor, split_size=None) -> List[torch.Tensor]:
         else:
             raise ValueError("Support only for 2-dimensional unbinded tensor. Split size for more dimensions provided")
     return items
+
+
+# ---------------------------------------------------------------------- viewer helpers (reference :127-178)
+def img_to_b64str(img, quality: int = 95) -> str:
+    """uint8 (H, W) or (H, W, 3) array -> "data:image/jpeg;base64,..." (JPEG through PIL; the reference uses cv2)."""
+    import base64
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    if not isinstance(img, np.ndarray):
+        raise TypeError(f"img must be of type np.ndarray, but was {type(img)}")
+    if img.ndim != 2 and img.ndim != 3:
+        raise ValueError(f"img.ndim must be 2 or 3, but was {img.ndim}")
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="JPEG", quality=quality)
+    return "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode("utf-8")
+
+
+def numpy_to_plotly_image(img, name=None, is_depth: bool = False, scale=None, quality: int = 95):
+    """`plotly.graph_objects.Image` of an RGB or depth array with a hover label (colour / depth, optional scale)."""
+    import plotly.graph_objects as go
+
+    what, value = ("depth", "%{z[0]}") if is_depth else ("color", "[%{z[0]}, %{z[1]}, %{z[2]}]")
+    hover = "x: %{x}<br>y: %{y}<br>" + what + ": " + value
+    if scale is not None:
+        scale = int(scale) if int(scale) == scale else scale
+        hover += f"<br>scale: x{scale}<br>"
+    return go.Image(source=img_to_b64str(img, quality), hovertemplate=hover + "<extra></extra>", name=name)

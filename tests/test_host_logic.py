@@ -305,3 +305,18 @@ def test_pointclouds_plotly_export():
     assert len(fig.data) == 1 and len(fig.data[0].x) == 10
     with pytest.raises(TypeError):
         pc.plotly("0")
+
+
+def test_rgbdimages_plotly_export():
+    """Animated viewer export (reference structures/rgbdimages.py:764-900, structutils.py:127-178)."""
+    import gradslam_amd as gs
+
+    torch.manual_seed(0)
+    r = gs.RGBDImages(torch.rand(2, 3, 12, 16, 3), torch.rand(2, 3, 12, 16, 1) + 0.5, torch.eye(4).view(1, 1, 4, 4).repeat(2, 1, 1, 1))
+    frames = r.plotly(1, as_figure=False)
+    assert len(frames) == 3 and len(frames[0]["data"]) == 2 and frames[2]["name"] == 2
+    assert frames[0]["data"][0].source.startswith("data:image/jpeg;base64,") and "depth" in frames[0]["data"][1].hovertemplate
+    fig = r.plotly(0, include_depth=False)
+    assert len(fig.frames) == 3 and len(fig.layout.sliders[0].steps) == 3
+    with pytest.raises(TypeError):
+        r.plotly(0.0)
