@@ -720,3 +720,22 @@ def test_short_loops_match_the_per_op_formulation(gs, golden, grad_lm):
             assert ia is None and ib is None and torch.equal(Ta, T0)
         else:
             assert torch.equal(ia, ib) and torch.equal(ia, ic), numiters
+
+
+@pytest.mark.parametrize("kind", ["sorted", "random", "clustered"])
+def test_knn_large_target_equals_bruteforce(gs, kind):
+    """200 k targets (several rounds of the LDS survivor list per tile): the pruned search must stay the brute-force
+    scan's, bit for bit, whether the boxes prune a lot (sorted / clustered clouds) or nothing (random)."""
+    torch.manual_seed(5)
+    ns, nt = 6000, 200000 + 37
+    src, tgt = torch.randn(ns, 3, device=DEV), torch.randn(nt, 3, device=DEV)
+    if kind == "sorted":
+        tgt = tgt[tgt[:, 0].argsort()].contiguous()
+    elif kind == "clustered":
+        centres = torch.randn(nt // 250 + 1, 3, device=DEV) * 3
+        tgt = (centres.repeat_interleave(250, 0)[:nt] + 0.01 * torch.randn(nt, 3, device=DEV)).contiguous()
+        src = (centres[torch.randint(0, centres.shape[0], (ns,), device=DEV)] + 0.02 * torch.randn(ns, 3, device=DEV)).contiguous()
+        tgt[1000:1010] = tgt[2000:2010].clone()   # exact duplicates far apart in index: lowest index must win
+    a = gs.ops.knn1_raw(src, tgt)
+    b = gs.ops.knn1_raw(src, tgt, brute_force=True)
+    assert torch.equal(a, b)
