@@ -1249,7 +1249,19 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     int cur = 0;            // buffer the next launch READS its state / the previous sums from
     int pending = -1;       // step waiting to be folded into the next association
     int pending_slot = -1;  // slot the association before that step wrote (tape mode)
+    // Folding pays while the association's blocks all run at once (latency-bound regime: the step's ~4 us ride in
+    // every block instead of a ~4.5 us launch).  With more tiles than the chip holds (2 x 1024-thread blocks per CU)
+    // the kernel is throughput-bound and 4 us of redundant work in EVERY block costs more than one small launch:
+    // then each step is a launch of its own again (measured at 78 k source points: 1225 blocks).
+    const bool fold = (int)kgrid.x <= 2 * 256;
     auto assoc = [&](int first) {
+        if (!fold && pending >= 0) {  // stand-alone step, state updated in place
+            hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S[cur], w.partials[cur], lb, pending, gp, trace, out_T,
+                               pending_slot, tape ? tp.rec + (size_t)n_step * REC_WORDS : nullptr, 1, (const float *)nullptr,
+                               (float *)nullptr);
+            ++n_step;
+            pending = -1;
+        }
         const int nxt = pending >= 0 ? 1 - cur : cur;  // a folded step publishes the new state to the other buffer
         prof_mark(0, 0, st);
         hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S[cur], w.S[nxt], w.partials[cur], lb, pending, gp, trace,
