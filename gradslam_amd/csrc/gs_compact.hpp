@@ -177,6 +177,19 @@ static inline int compact_launch(int64_t n, Pred pred, Writer writer, int *d_out
 // MultiWriter that appends: selected rows go behind the *base rows a destination already holds (device-side
 // count), rows that would not fit into `cap` are dropped (the caller sizes cap so that this never happens and
 // checks the overflow flag)
+// one row of `w` 32-bit words from src row i to dst row j; the common widths are spelled out so that the three
+// words of an xyz / rgb row travel as one dwordx3 access instead of three dword accesses
+__device__ __forceinline__ void copy_row(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t i, int64_t j, int w) {
+    if (w == 3) {
+        const uint32_t a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];
+        dst[3 * j] = a; dst[3 * j + 1] = b; dst[3 * j + 2] = c;
+    } else if (w == 1) {
+        dst[j] = src[i];
+    } else {
+        for (int k = 0; k < w; ++k) dst[j * w + k] = src[i * w + k];
+    }
+}
+
 struct AppendWriter {
     const uint32_t *src[4];
     uint32_t *out[4];
@@ -190,8 +203,7 @@ struct AppendWriter {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             if (a >= n_arrays) break;
-            const int w = words[a];
-            for (int k = 0; k < w; ++k) out[a][at * w + k] = src[a][i * w + k];
+            copy_row(src[a], out[a], i, at, words[a]);
         }
     }
 };

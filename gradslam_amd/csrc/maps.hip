@@ -391,8 +391,7 @@ struct MultiWriter {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             if (a >= n_arrays) break;
-            const int w = words[a];
-            for (int k = 0; k < w; ++k) out[a][pos * w + k] = src[a][i * w + k];
+            copy_row(src[a], out[a], i, pos, words[a]);
         }
     }
 };
