@@ -22,8 +22,9 @@ template <class W, class = void>
 struct writer_has_skip : std::false_type {};
 template <class W>
 struct writer_has_skip<W, std::void_t<decltype(&W::skip)>> : std::true_type {};
-// a Pred may provide block_init(), run once by every block of both passes before the first item (followed by a
-// barrier): per-block constants go to LDS there instead of costing a preparation launch
+// a Pred may provide block_init(pass), run once by every block of both passes (pass 0 = count, 1 = write) before
+// the first item and followed by a barrier: per-block constants go to LDS there, and small side jobs ride along,
+// instead of costing a preparation launch
 template <class P, class = void>
 struct pred_has_block_init : std::false_type {};
 template <class P>
@@ -41,7 +42,7 @@ template <class Pred>
 __global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts) {
     __shared__ int sm[kCT / 64];
     if constexpr (pred_has_block_init<Pred>::value) {
-        pred.block_init();
+        pred.block_init(0);
         __syncthreads();
     }
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
                                                        int *__restrict__ out_total = nullptr) {
     __shared__ int sm[kCT / 64 + 1];
     if constexpr (pred_has_block_init<Pred>::value) {
-        pred.block_init();
+        pred.block_init(1);
         __syncthreads();
     }
     const int block_base = SelfScan ? self_scan_offset(block_offsets, out_total) : block_offsets[blockIdx.x];

@@ -120,7 +120,7 @@ struct ActivePredL {
     const float *poses, *Ks;
     int B, Nmax, H, W, ds;
     float umax, vmax;
-    __device__ void block_init() const {
+    __device__ void block_init(int /*pass*/) const {
         for (int b = threadIdx.x; b < B; b += blockDim.x) cam_cache()[b] = make_cam(poses + 16 * b, Ks + 16 * b);
     }
     __device__ bool operator()(int64_t i) const {
@@ -143,6 +143,45 @@ struct ActiveWriterL {
         longlong4 r;  // one 32-byte store per row
         r.x = b; r.y = n; r.z = h; r.w = w;
         *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
+    }
+};
+
+// The same projection for ONE sequence when its result feeds the ICP target build: the count pass also zeroes
+// the per-pixel counters, the write pass also builds the per-pixel histogram of the ds-grid rows (what
+// tgt_init_k and tgt_gather_count_k's counting would do in two more launches).
+struct ActivePredH {
+    const float *points;
+    const int32_t *counts;
+    const float *poses, *Ks;
+    int Nmax, H, W, ds;
+    float umax, vmax;
+    int *cnt, *fill;  // (npix) each
+    int npix;
+    __device__ void block_init(int pass) const {
+        if (threadIdx.x == 0) cam_cache()[0] = make_cam(poses, Ks);
+        if (pass == 0)
+            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) { cnt[i] = 0; fill[i] = 0; }
+    }
+    __device__ bool operator()(int64_t i) const {
+        if (i >= counts[0]) return false;
+        int h, w;
+        if (!project_point(cam_cache()[0], ld3(points, i), H, W, umax, vmax, h, w)) return false;
+        return (h % ds == 0) && (w % ds == 0);
+    }
+};
+struct ActiveWriterH {
+    const float *points;
+    int64_t *rows;
+    int H, W, ds, Wd;
+    float umax, vmax;
+    int *cnt;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        int h, w;
+        project_point(cam_cache()[0], ld3(points, i), H, W, umax, vmax, h, w);
+        longlong4 r;
+        r.x = 0; r.y = i; r.z = h; r.w = w;
+        *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
+        atomicAdd(cnt + (h / ds) * Wd + (w / ds), 1);
     }
 };
 
@@ -281,6 +320,30 @@ __global__ void tgt_gather_count_k(const int64_t *__restrict__ rows, const int32
     }
 }
 
+// one sequence: reference-order target arrays (gather) and the pixel-ordered copy (scatter) in one pass
+__global__ void tgt_scatter_gather1_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
+                                      const float *__restrict__ map_points, const float *__restrict__ map_normals, int cap,
+                                      float *__restrict__ tgt, float *__restrict__ tnrm, int32_t *__restrict__ counts,
+                                      int32_t *__restrict__ tgt_index, int Wd, int ds, const int *__restrict__ start,
+                                      int *__restrict__ fill, float *__restrict__ scan_pts, int32_t *__restrict__ scan_orig) {
+    const int n = *d_n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
+        const f3 p = ld3(map_points, r.y);
+        if (i < cap) {
+            st3(tgt, i, p);
+            st3(tnrm, i, ld3(map_normals, r.y));
+            if (tgt_index) tgt_index[i] = (int32_t)r.y;
+        }
+        const int pix = (int)(r.z / ds) * Wd + (int)(r.w / ds);
+        const int slot = start[pix] + atomicAdd(fill + pix, 1);
+        if (slot >= cap) continue;
+        st3(scan_pts, slot, p);
+        scan_orig[slot] = (int32_t)i;
+    }
+}
+
 __global__ void fill_i32b_k(int *__restrict__ p, int64_t n, int v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -319,6 +382,42 @@ int gs_project_active(const float *points, const int32_t *counts, int B, int Nma
     ActiveWriter wr{points, cams, out_rows, Nmax, H, W, umax, vmax};
     return compact_launch((int64_t)B * Nmax, pred, wr, out_count, cws, st, "gs_project_active");
 }
+
+}  // extern "C"
+
+namespace gs {
+// gs_project_active (ds-grid) + gs_build_icp_target for one sequence in 4 launches instead of 6 (see ActivePredH)
+size_t project_target1_ws_bytes(int H, int W, int ds, int Nmax) {
+    const size_t npix = (size_t)cdiv(H, ds) * cdiv(W, ds);
+    return compact_ws_bytes(Nmax) + 2 * align_up(npix * 4, 256);
+}
+int project_target1(const float *points, const int32_t *counts, int Nmax, const float *poses, const float *intrinsics, int H,
+                    int W, int ds, const float *map_normals, int cap, int64_t *rows, int32_t *nrows, float *tgt, float *tnrm,
+                    int32_t *nt, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, void *ws,
+                    size_t ws_bytes, hipStream_t st) {
+    const char *name = "gs_slam_localize/target";
+    if (!ws || ws_bytes < project_target1_ws_bytes(H, W, ds, Nmax)) {
+        set_error("%s: workspace too small", name);
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    const int Wd = cdiv(W, ds), npix = cdiv(H, ds) * Wd;
+    char *p = (char *)ws;
+    void *cws = p; p += compact_ws_bytes(Nmax);
+    int *cnt = (int *)p, *fill = (int *)(p + align_up((size_t)npix * 4, 256));
+    const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
+    ActivePredH pred{points, counts, poses, intrinsics, Nmax, H, W, ds, umax, vmax, cnt, fill, npix};
+    ActiveWriterH wr{points, rows, H, W, ds, Wd, umax, vmax, cnt};
+    const int rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pix_scan_k, dim3(1), dim3(1024), 0, st, cnt, npix, pix_start);
+    hipLaunchKernelGGL(tgt_scatter_gather1_k, dim3(min(cdiv(Nmax, 256), 1024)), dim3(256), 0, st, rows, nrows, points, map_normals, cap,
+                       tgt, tnrm, nt, tgt_index, Wd, ds, pix_start, fill, scan_points, scan_orig);
+    GS_LAUNCH_CHECK(name);
+    return GS_OK;
+}
+}  // namespace gs
+
+extern "C" {
 
 size_t gs_gather_table_rows_ws_bytes(int B) { return align_up(sizeof(int32_t) * (size_t)(B + 1), 256); }
 

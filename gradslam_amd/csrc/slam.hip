@@ -78,6 +78,13 @@ __global__ void eye4_k(float *__restrict__ T, int B) {
     if (i < 16 * B) T[i] = ((i % 16) % 5 == 0) ? 1.0f : 0.0f;
 }
 
+// project.hip: active-point projection on the ds grid + ICP target build for one sequence, 4 launches
+size_t project_target1_ws_bytes(int H, int W, int ds, int Nmax);
+int project_target1(const float *points, const int32_t *counts, int Nmax, const float *poses, const float *intrinsics, int H,
+                    int W, int ds, const float *map_normals, int cap, int64_t *rows, int32_t *nrows, float *tgt, float *tnrm,
+                    int32_t *nt, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, void *ws,
+                    size_t ws_bytes, hipStream_t st);
+
 struct LocWs {
     float *src;        // (B, capS, 3)
     int32_t *src_pix;  // (B, capS) ds-grid pixel of every source point
@@ -120,6 +127,7 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     sub = std::max(sub, gs_gather_table_rows_ws_bytes(B));
     sub = std::max(sub, gs_bucket_by_pixel_ws_bytes(B, H, W, ds));
     sub = std::max(sub, gs_icp_ws_bytes(capS, capT));
+    sub = std::max(sub, project_target1_ws_bytes(H, W, ds, Nmax));
     const size_t o_sub = take(sub);
     if (ws && out) {
         char *p = (char *)ws;
@@ -317,12 +325,17 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.src_pix, w.ns,
                                   w.sub, w.sub_bytes, stream))) return rc;
     // map points that land on the ds-grid of the previous frame: the ICP target
-    if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
-                                w.sub_bytes, stream))) return rc;
-    // reference-order target (points, normals, counts) + the same points in pixel order and one seed
-    // per ds-grid pixel (search hints only)
-    if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
-                                  w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.sub, w.sub_bytes, stream))) return rc;
+    // reference-order target (points, normals, counts) + the same points in pixel order and the first scan
+    // slot of every ds-grid pixel (search hints only); one sequence takes the 4-launch fused form
+    if (B == 1) {
+        if ((rc = project_target1(map_points, map_counts, Nmax, prev_poses, intrinsics, H, W, ds, map_normals, capT, w.rows, w.nrows,
+                                  w.tgt, w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.sub, w.sub_bytes, st))) return rc;
+    } else {
+        if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
+                                    w.sub_bytes, stream))) return rc;
+        if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
+                                      w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.sub, w.sub_bytes, stream))) return rc;
+    }
     // fold_compose: the loop's last launch also writes out_poses = T . prev_poses.  Only for eager launches: a
     // captured graph must not bake the caller's prev_poses / out_poses addresses in (they change every call).
     auto enqueue_loops = [&](gs_stream_t s, bool fold_compose) -> int {
@@ -489,10 +502,16 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
     int rc;
     if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, tp.src, nullptr, nullptr, tp.src_pix, tp.ns,
                                   w.sub, w.sub_bytes, stream))) return rc;
-    if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
-                                w.sub_bytes, stream))) return rc;
-    if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
-                                  w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.sub, w.sub_bytes, stream))) return rc;
+    if (B == 1) {
+        if ((rc = project_target1(map_points, map_counts, Nmax, prev_poses, intrinsics, H, W, ds, map_normals, capT, w.rows, w.nrows,
+                                  w.tgt, w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.sub, w.sub_bytes,
+                                  (hipStream_t)stream))) return rc;
+    } else {
+        if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
+                                    w.sub_bytes, stream))) return rc;
+        if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
+                                      w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.sub, w.sub_bytes, stream))) return rc;
+    }
     for (int b = 0; b < B; ++b) {
         const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, tp.src_pix + (size_t)b * capS,
                                  w.pix_start + (size_t)b * (capS + 1), cdiv(W, ds), cdiv(H, ds)};
