@@ -20,6 +20,7 @@ bounded sample of the same workload on the host cores (rank 0, N=1 only).
 """
 import argparse
 import ctypes
+import gc
 import json
 import math
 import os
@@ -230,10 +231,18 @@ def main():
         # of a torch kernel in a process lazily loads its code object -- ~7 ms the first time on a fresh box)
         p0 = p0 if p0 is not None else one_step(gs, slam, world_map, prev, lives[0], K)
         parallel.gather_poses(torch.cat([p0] * max(args.steps, 1), 1), world)
+        # A full (generation-2) pass of Python's cyclic collector over the ~1e6 objects that importing torch leaves
+        # behind takes ~40 ms -- 180 steps' worth -- and, allocation counts being deterministic, it landed on step 30
+        # of every run.  What long-running services do: collect now, then freeze the survivors out of future passes.
+        gc.collect()
+        gc.freeze()
         barrier()
         t0 = time.perf_counter()
+        marks = []
         for i in range(args.steps):
             poses.append(one_step(gs, slam, world_map, prev, lives[i % N_LIVE], K))
+            if os.environ.get("GS_BENCH_TRACE"):
+                marks.append(time.perf_counter() - t0)
         t_enq = time.perf_counter() - t0
         local_poses = torch.cat(poses, 1)                      # (1, K, 4, 4)
         all_poses = parallel.gather_poses(local_poses, world)  # final RCCL gather of the poses
@@ -246,6 +255,7 @@ def main():
             print("[trace] enqueue %.3f ms, +cat/gather %.3f ms, total %.3f ms | launch policy: %d eager enqueues timed, min %.2f us "
                   "per launch, %d graphs captured, %d replays" % (1e3 * t_enq, 1e3 * t_gat, 1e3 * dt, st[0], st[1], st[2], st[3]),
                   file=sys.stderr)
+            print("[trace] per-step host ms:", " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip([0.0] + marks[:-1], marks)), file=sys.stderr)
         # per-kernel durations: a second, short pass of the same steps with HIP events recorded around the
         # hot kernel on its launch stream (events force eager launches; the timed region above runs in the
         # library's automatic mode: eager launches on a fast host, hipGraph replay of the loop on a slow one)
