@@ -739,3 +739,31 @@ def test_knn_large_target_equals_bruteforce(gs, kind):
     a = gs.ops.knn1_raw(src, tgt)
     b = gs.ops.knn1_raw(src, tgt, brute_force=True)
     assert torch.equal(a, b)
+
+
+def test_degenerate_frames_streamed_and_stepwise(gs):
+    """Ragged / empty inputs: one sequence of a batch of two loses a whole frame (all-zero depth), the other a
+    block of rows.  Nothing may crash or go non-finite; the empty frame leaves the pose where it was and appends
+    nothing; the streamed driver still equals the step-by-step path bit for bit."""
+    import warnings
+
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(2, 5, 120, 160, seed=31)
+    dd = dd.clone()
+    dd[0, 2] = 0.0            # sequence 0: frame 2 has no valid pixel at all
+    dd[1, 3, :60] = 0.0       # sequence 1: frame 3 lost its upper half
+    frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
+    out = {}
+    for streamed in (True, False):
+        slam = gs.slam.PointFusion(odom="icp", dsratio=2, numiters=5, device=DEV)
+        slam.streamed = streamed
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[streamed] = slam(frames)
+    (pa, qa), (pb, qb) = out[True], out[False]
+    assert torch.isfinite(qa).all() and torch.equal(qa, qb)
+    assert torch.equal(qa[0, 2], qa[0, 1])                     # nothing to align: the pose stays
+    assert pa.num_points_per_pointcloud.tolist() == pb.num_points_per_pointcloud.tolist()
+    for b in range(2):
+        assert torch.equal(pa.points_list[b], pb.points_list[b]) and torch.isfinite(pa.points_list[b]).all()
