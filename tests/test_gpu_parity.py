@@ -767,3 +767,64 @@ def test_degenerate_frames_streamed_and_stepwise(gs):
     assert pa.num_points_per_pointcloud.tolist() == pb.num_points_per_pointcloud.tolist()
     for b in range(2):
         assert torch.equal(pa.points_list[b], pb.points_list[b]) and torch.isfinite(pa.points_list[b]).all()
+
+
+def test_arena_entry_points_against_torch(gs):
+    """The two arena primitives of the C ABI called directly: gs_append_rows (device-side append offset, capacity
+    clamp, overflow flag) and gs_fusion_merge_inplace (== gs_fusion_merge on the rows that exist, no-op without
+    correspondences)."""
+    import ctypes
+
+    from gradslam_amd import _native as nv
+    from gradslam_amd import ops
+
+    torch.manual_seed(3)
+    n, cap = 5000, 6000
+    a, b = torch.randn(n, 3, device=DEV), torch.randn(n, 1, device=DEV)
+    mask = (torch.rand(n, device=DEV) < 0.3).to(torch.uint8)
+    dst_a, dst_b = torch.zeros(cap, 3, device=DEV), torch.zeros(cap, 1, device=DEV)
+    dst_a[:4000], dst_b[:4000] = 7.0, 7.0
+    count = torch.tensor([4000], dtype=torch.int32, device=DEV)
+    appended, overflow = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = nv.workspace(nv.ws_bytes("gs_append_rows_ws_bytes", n), a.device, "append_test")
+    src = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    dst = (ctypes.c_void_p * 2)(dst_a.data_ptr(), dst_b.data_ptr())
+    widths = (ctypes.c_int * 2)(3, 1)
+    nv.call("gs_append_rows", 2, src, widths, dst, nv.ptr(mask), n, nv.ptr(count), cap, nv.ptr(appended), nv.ptr(overflow),
+            nv.ptr(ws), ws.numel(), nv.stream())
+    sel = a[mask.bool()]
+    k = sel.shape[0]
+    assert int(count) == 4000 + k and int(appended) == k and int(overflow) == 0
+    assert torch.equal(dst_a[4000:4000 + k], sel) and torch.equal(dst_b[4000:4000 + k], b[mask.bool()])
+    assert (dst_a[:4000] == 7.0).all() and (dst_a[4000 + k:] == 0).all()
+    # capacity clamp
+    count.fill_(cap - 10)
+    nv.call("gs_append_rows", 2, src, widths, dst, nv.ptr(mask), n, nv.ptr(count), cap, nv.ptr(appended), nv.ptr(overflow),
+            nv.ptr(ws), ws.numel(), nv.stream())
+    assert int(count) == cap and int(appended) == 10 and int(overflow) == 1 and torch.equal(dst_a[cap - 10:], sel[:10])
+
+    # in-place merge against the out-of-place one
+    B, H, W, N = 1, 24, 32, 900
+    gV, gN, rgb = (torch.randn(B, 1, H, W, 3, device=DEV) for _ in range(3))
+    alpha = torch.rand(B, 1, H, W, 1, device=DEV)
+    mp, mn, mc = (torch.randn(B, N, 3, device=DEV) for _ in range(3))
+    cc = torch.rand(B, N, 1, device=DEV) + 0.5
+    live = 700                                    # rows beyond the count are padding
+    for t in (mp, mn, mc, cc):
+        t[:, live:] = 0
+    counts = torch.tensor([live], dtype=torch.int32, device=DEV)
+    pix = torch.randperm(H * W, device=DEV)[:300]
+    rows = torch.stack([torch.zeros(300, dtype=torch.int64, device=DEV), torch.randperm(live, device=DEV)[:300], pix // W, pix % W], 1).contiguous()
+    for n_rows in (300, 0):
+        d_n = ops.dev_int(n_rows, DEV)
+        ref = ops.fusion_merge_raw(rows, d_n, 300, gV, gN, rgb, alpha, counts, mp, mn, mc, cc)
+        got = [t.clone() for t in (mp, mn, mc, cc)]
+        ws = nv.workspace(nv.ws_bytes("gs_fusion_merge_inplace_ws_bytes", B, N), mp.device, "merge_test")
+        nv.call("gs_fusion_merge_inplace", nv.ptr(rows), nv.ptr(d_n), 300, nv.ptr(gV), nv.ptr(gN), nv.ptr(rgb), nv.ptr(alpha), B, H, W,
+                N, nv.ptr(counts), nv.ptr(got[0]), nv.ptr(got[1]), nv.ptr(got[2]), nv.ptr(got[3]), nv.ptr(ws), ws.numel(), nv.stream())
+        if n_rows:
+            for x, y in zip(got, ref):
+                assert torch.equal(x, y)
+        else:  # no correspondence: untouched (fuse_with_map skips the merge), whereas the formula would re-round every point
+            for x, y in zip(got, (mp, mn, mc, cc)):
+                assert torch.equal(x, y)
