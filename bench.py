@@ -299,7 +299,8 @@ def main():
                                    "dsratio 4 (~19k x ~19k points), 10 LM iterations, map {} points".format(n_map),
                        "parallelism": "one sequence per GPU, final RCCL all_gather of poses", "pose_max_abs_err": pose_err},
             "roofline_timed_region": {
-                "kernel": "knn1_loop_k (K+J fused: rigid transform, exact 1-NN association with fp32-exact AABB pruning, "
+                "kernel": "knn1_loop_k (X+K+J fused: the previous iteration's O(1) step -- reduce, LM decision, 6x6 solve, exp -- "
+                          "in the prologue, then rigid transform, exact 1-NN association with fp32-exact AABB pruning, "
                           "Jacobian rows and 29-term reduce of its 64-point tile)",
                 "launches": n_knn, "avg_launch_ms": round(avg_knn_ms, 5),
                 "timing_source": "HIP events on the launch stream, second eager pass of {} steps".format(n_prof),
