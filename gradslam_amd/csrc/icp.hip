@@ -755,20 +755,6 @@ __device__ __noinline__ void se3_exp_dev(const float *xi, float *T) {
     T[12] = 0.0f; T[13] = 0.0f; T[14] = 0.0f; T[15] = 1.0f;
 }
 
-// C = A . B for 4x4 (torch.mm contraction: fma chain over k)
-__device__ void mm4(const float *A, const float *B, float *C) {
-    float r[16];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            float v = A[4 * i] * B[j];
-            v = __fmaf_rn(A[4 * i + 1], B[4 + j], v);
-            v = __fmaf_rn(A[4 * i + 2], B[8 + j], v);
-            v = __fmaf_rn(A[4 * i + 3], B[12 + j], v);
-            r[4 * i + j] = v;
-        }
-    for (int i = 0; i < 16; ++i) C[i] = r[i];
-}
-
 enum StepMode { STEP_ADOPT = 0, STEP_LM = 1, STEP_GRAD_B = 2 };
 
 // Tape record of one step (REC_WORDS floats): the IcpState BEFORE the step, then what the step saw.
@@ -786,12 +772,6 @@ struct GradParams {
     float lambda_min, range, B, B2, inv_nu;
 };
 
-__device__ __forceinline__ void adopt_look(IcpState *S, const float *lin, int look_slot) {
-#pragma unroll 11
-    for (int i = 0; i < 44; ++i) S->cur[i] = lin[i];
-    S->p_cur = look_slot >= 0 ? look_slot : 1 - S->p_cur;
-    S->b_cur = look_slot >= 0 ? look_slot : 1 - S->b_cur;
-}
 
 // x = (H + damp I)^-1 g by ONE WAVE: Gauss-Jordan on the augmented 6x7 system in fp64, element (i, k) in
 // lane 8 i + k, rows / columns exchanged with lane permutes.  Takes ~0.5 us like a fully unrolled
@@ -822,89 +802,91 @@ __device__ void solve6_wave(const float *H, const float *g, float damp, float *x
     if (!ok && lane == 0) solve6_lu(H, g, damp, x, lu_buf);     // `ok` is wave-uniform: every lane saw the same pivots
 }
 
-// The O(1) step in three parts, so that the solve can be the wave-parallel one:
-//   step_decide (one lane): reduce result -> LM / gradLM state machine; returns whether a solve follows
-//   solve6_wave (wave 0)
-//   step_finish (one lane): dT = exp(xi)
+// The O(1) step by a block (>= 64 threads, all of them call this; S and acc in LDS).  Wave 0 does the work, spread
+// over its lanes where the data is wide -- expanding the 29 sums to H | g | e | n, adopting them, T = dT . T, the
+// tape / trace records -- so that the serial part is a handful of scalars:
 //   STEP_ADOPT : the look-ahead cloud becomes the current one unconditionally (initial cloud; gradICP's
 //                re-linearisation)                          -> solve ; dT = exp(xi)
 //   STEP_LM    : look-ahead cloud: accept (adopt, damp/2, T = dT T) or reject (damp*2) -> solve ; dT
 //   STEP_GRAD_B: look-ahead error -> damp, sigma ; dT = exp(sigma xi) ; T = dT T ; look-ahead discarded
-__device__ bool step_decide(IcpState *S, const float *acc, int mode, GradParams gp, float *__restrict__ trace,
-                                         float *__restrict__ out_T, int look_slot, float *__restrict__ rec,
-                                         float *lin /* 44 floats of LDS: keeps the expansion out of the register file */) {
-    expand44(acc, lin);
-    if (rec) {  // tape: what the look-ahead launch measured, where it wrote, what this step is
-#pragma unroll 8
-        for (int i = 0; i < 44; ++i) rec[REC_LIN + i] = lin[i];
-        rec[REC_SLOT] = (float)look_slot;
-        rec[REC_MODE] = (float)mode;
-        rec[REC_ACCEPT] = (mode == STEP_LM) ? ((lin[42] < S->cur[42]) ? 1.0f : 0.0f) : 1.0f;
+// `solve` = false for a loop's very last step, whose xi / dT nothing consumes.
+__device__ __forceinline__ float expand_elem(const float *acc, int t) {  // element t of the 44 from the 29 sums
+    if (t < 36) {
+        int u = t / 6, v = t % 6;
+        if (u > v) { const int w = u; u = v; v = w; }
+        return acc[u * 6 - (u * (u - 1)) / 2 + (v - u)];
     }
-    bool solve = true;
-    if (mode == STEP_ADOPT) {
-        adopt_look(S, lin, look_slot);
-        S->b_first = S->b_cur;
-    } else if (mode == STEP_LM) {
-        const float err = S->cur[42], new_err = lin[42];
-        const bool accept = new_err < err;
-        if (trace) {
-            float *t = trace + 48 * S->it;
-#pragma unroll 8
-            for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
-            t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = accept ? 1.0f : 0.0f; t[46] = S->cur[43];
-            t[47] = 0.0f;
-        }
-        S->b_first = S->b_cur;
-        if (accept) {
-            adopt_look(S, lin, look_slot);
-            S->damp = S->damp / 2.0f;
-            mm4(S->dT, S->T, S->T);
-        } else {
-            S->damp = S->damp * 2.0f;  // the look-ahead buffers are simply overwritten next time
-        }
-        S->it += 1;
-    } else {  // STEP_GRAD_B
-        const float err = S->cur[42], new_err = lin[42];
-        float diff = new_err - err;
-        diff = fminf(fmaxf(diff, -70.0f), 70.0f);
-        const float damp_new = gp.lambda_min + gp.range / (1.0f + expf((-gp.B) * diff));
-        if (trace) {
-            float *t = trace + 48 * S->it;
-#pragma unroll 8
-            for (int i = 0; i < 42; ++i) t[i] = S->cur[i];
-            t[42] = err; t[43] = new_err; t[44] = S->damp; t[45] = 1.0f; t[46] = S->cur[43]; t[47] = 0.0f;
-        }
-        S->b_first = S->b_cur;
-        S->damp = S->damp * damp_new;
-        const float sig = 1.0f / powf(1.0f + expf((-gp.B2) * diff), gp.inv_nu);
-        float *sx = lin;  // LDS scratch again (lin is dead by now): no stack for the non-inlined exp
-#pragma unroll 8
-        for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
-        se3_exp_dev(sx, S->dT);
-        mm4(S->dT, S->T, S->T);
-        S->it += 1;  // the next launch re-derives the cloud from pts[p_cur] with the damped step
-        solve = false;
-    }
-    if (out_T) {
-#pragma unroll 8
-        for (int i = 0; i < 16; ++i) out_T[i] = S->T[i];
-    }
-    return solve;
+    if (t < 42) return acc[21 + (t - 36)];
+    return t == 42 ? acc[27] : acc[28];
 }
-
-// Whole step by a block (>= 64 threads, all of them call this): S and acc in LDS.  `solve` = false for a loop's
-// very last step, whose xi / dT nothing consumes.
 __device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mode, GradParams gp, float *trace, float *out_T,
                                            int look_slot, float *rec, double *lu_buf, bool solve) {
-    __shared__ int need_solve;
-    __shared__ float lin_sm[44];
-    if (threadIdx.x == 0) need_solve = (step_decide(S, acc, mode, gp, trace, out_T, look_slot, rec, lin_sm) && solve) ? 1 : 0;
+    __shared__ float lin[44];
+    __shared__ float sx[6];
+    const int t = threadIdx.x;
+    if (t < 44) lin[t] = expand_elem(acc, t);
     __syncthreads();
-    if (need_solve) {  // block-uniform
-        if (threadIdx.x < 64) solve6_wave(S->cur, S->cur + 36, S->damp, S->xi, lu_buf);
+    const float err = S->cur[42], new_err = lin[42];
+    const bool lm_accept = new_err < err;
+    const bool adopt = mode == STEP_ADOPT || (mode == STEP_LM && lm_accept);
+    if (rec) {  // tape: what the look-ahead launch measured, where it wrote, what this step is
+        if (t < 44) rec[REC_LIN + t] = lin[t];
+        if (t == 44) {
+            rec[REC_SLOT] = (float)look_slot;
+            rec[REC_MODE] = (float)mode;
+            rec[REC_ACCEPT] = (mode == STEP_LM) ? (lm_accept ? 1.0f : 0.0f) : 1.0f;
+        }
+    }
+    if (trace && mode != STEP_ADOPT) {
+        float *tr = trace + 48 * S->it;
+        if (t < 42) tr[t] = S->cur[t];
+        if (t == 42) {
+            tr[42] = err; tr[43] = new_err; tr[44] = S->damp; tr[45] = (mode == STEP_LM && !lm_accept) ? 0.0f : 1.0f;
+            tr[46] = S->cur[43]; tr[47] = 0.0f;
+        }
+    }
+    if (mode == STEP_GRAD_B) {  // the gates and the damped step: a few scalars, one lane
+        if (t == 0) {
+            float diff = new_err - err;
+            diff = fminf(fmaxf(diff, -70.0f), 70.0f);
+            const float damp_new = gp.lambda_min + gp.range / (1.0f + expf((-gp.B) * diff));
+            S->damp = S->damp * damp_new;
+            const float sig = 1.0f / powf(1.0f + expf((-gp.B2) * diff), gp.inv_nu);
+            for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
+            se3_exp_dev(sx, S->dT);
+        }
         __syncthreads();
-        if (threadIdx.x == 0) se3_exp_dev(S->xi, S->dT);
+    }
+    // T = dT . T  (accepted LM step, every gradLM step): one lane per element, torch.mm's fma chain over k
+    const bool mul_T = mode == STEP_GRAD_B || (mode == STEP_LM && lm_accept);
+    float new_T = 0.0f;
+    if (mul_T && t < 16) {
+        const int i = t >> 2, j = t & 3;
+        float v = S->dT[4 * i] * S->T[j];
+        v = __fmaf_rn(S->dT[4 * i + 1], S->T[4 + j], v);
+        v = __fmaf_rn(S->dT[4 * i + 2], S->T[8 + j], v);
+        v = __fmaf_rn(S->dT[4 * i + 3], S->T[12 + j], v);
+        new_T = v;
+    }
+    __syncthreads();  // the old state has been read
+    if (adopt && t < 44) S->cur[t] = lin[t];
+    if (mul_T && t < 16) S->T[t] = new_T;
+    if (t == 0) {
+        if (mode != STEP_ADOPT) S->b_first = S->b_cur;  // the neighbour array the iteration's first solve used
+        if (adopt) {
+            S->p_cur = look_slot >= 0 ? look_slot : 1 - S->p_cur;
+            S->b_cur = look_slot >= 0 ? look_slot : 1 - S->b_cur;
+        }
+        if (mode == STEP_ADOPT) S->b_first = S->b_cur;
+        if (mode == STEP_LM) S->damp = lm_accept ? S->damp / 2.0f : S->damp * 2.0f;
+        if (mode != STEP_ADOPT) S->it += 1;
+    }
+    __syncthreads();
+    if (out_T && t < 16) out_T[t] = S->T[t];
+    if (solve && mode != STEP_GRAD_B) {  // block-uniform
+        if (t < 64) solve6_wave(S->cur, S->cur + 36, S->damp, S->xi, lu_buf);
+        __syncthreads();
+        if (t == 0) se3_exp_dev(S->xi, S->dT);
     }
     __syncthreads();
 }
