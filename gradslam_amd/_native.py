@@ -37,6 +37,8 @@ SIGNATURES = {
     "gs_fusion_merge_inplace_ws_bytes": (c_sz, [c_i, c_i]),
     "gs_fusion_merge_inplace": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
                                       c_sz, c_p]),
+    "gs_aggregate_update_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "gs_aggregate_update": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_sz, c_p]),
     "gs_pointfusion_update_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "gs_pointfusion_update": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_p, c_p,
                                     c_sz, c_p]),

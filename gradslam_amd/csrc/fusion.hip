@@ -118,6 +118,11 @@ struct AppendPredPix {
     __device__ bool operator()(int64_t i) const { return depth[i] > 0.0f && pix_n[i] == 0xffffffffu; }
 };
 
+struct ValidDepthPred {  // update_map_aggregate: every pixel with a valid depth (structures/utils.py:47-50)
+    const float *depth;
+    __device__ bool operator()(int64_t i) const { return depth[i] > 0.0f; }
+};
+
 // ------------------------------------------------------------------ F
 __global__ void fill_i32_k(int *__restrict__ p, int64_t n, int v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -418,6 +423,25 @@ int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const
     if (rc) return rc;
     hipLaunchKernelGGL(append_count_k, dim3(1), dim3(64), 0, st, d_count, total, cap, d_appended, d_overflow);
     GS_LAUNCH_CHECK("gs_pointfusion_update/append count");
+    return GS_OK;
+}
+// valid pixels of batch element b (n_arrays row arrays) appended behind the rows its arena already holds
+int append_valid_pixels(int n_arrays, const float *depth_b, int64_t HW, const float *const *h_src, const int *h_row_floats,
+                        float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended, int32_t *d_overflow, void *cws,
+                        hipStream_t st) {
+    AppendWriter wr;
+    wr.n_arrays = n_arrays; wr.base = d_count; wr.cap = cap;
+    for (int a = 0; a < 4; ++a) {
+        wr.src[a] = a < n_arrays ? (const uint32_t *)h_src[a] : nullptr;
+        wr.out[a] = a < n_arrays ? (uint32_t *)h_dst[a] : nullptr;
+        wr.words[a] = a < n_arrays ? h_row_floats[a] : 0;
+    }
+    int *total = (int *)((char *)cws + compact_ws_bytes(HW));
+    ValidDepthPred pred{depth_b};
+    const int rc = compact_launch(HW, pred, wr, total, cws, st, "gs_aggregate_update/append");
+    if (rc) return rc;
+    hipLaunchKernelGGL(append_count_k, dim3(1), dim3(64), 0, st, d_count, total, cap, d_appended, d_overflow);
+    GS_LAUNCH_CHECK("gs_aggregate_update/append count");
     return GS_OK;
 }
 }  // namespace gs

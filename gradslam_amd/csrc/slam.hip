@@ -155,6 +155,10 @@ int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const
                             const int *h_row_floats, float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended,
                             int32_t *d_overflow, void *cws, hipStream_t st);
 
+int append_valid_pixels(int n_arrays, const float *depth_b, int64_t HW, const float *const *h_src, const int *h_row_floats,
+                        float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended, int32_t *d_overflow, void *cws,
+                        hipStream_t st);
+
 // ------------------------------------------------------------------ PointFusion map update on an arena
 struct FuseWs {
     float *V, *N, *gV, *gN, *alpha;  // (B,H,W,3) x4, (B,H,W)
@@ -470,6 +474,48 @@ int gs_pointfusion_update(const float *depth, const float *rgb, const float *int
     }
     if (stats) {
         hipLaunchKernelGGL(fuse_stats_k, dim3(1), dim3(64), 0, st, w.nrows, w.ucnt, w.overflow, w.max_dot, w.appended, B, stats);
+        GS_LAUNCH_CHECK(name);
+    }
+    return GS_OK;
+}
+
+size_t gs_aggregate_update_ws_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t npix = (size_t)B * H * W;
+    return 2 * align_up(npix * 12, 256) + 256 + align_up((size_t)B * 4, 256) + gs_compact_ws_bytes((int64_t)H * W) + 256;
+}
+
+int gs_aggregate_update(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H, int W,
+                        float *map_points, float *map_normals, float *map_colors, int32_t *map_counts, int Nmax, int32_t *stats,
+                        void *ws, size_t ws_bytes, gs_stream_t stream) {
+    const char *name = "gs_aggregate_update";
+    GS_REQUIRE(depth && rgb && intrinsics && poses && map_points && map_normals && map_colors && map_counts, "%s: NULL argument", name);
+    GS_REQUIRE(B > 0 && B <= 60 && H >= 2 && W >= 2 && Nmax > 0, "%s: bad shape", name);
+    if (!ws || ws_bytes < gs_aggregate_update_ws_bytes(B, H, W)) {
+        set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, gs_aggregate_update_ws_bytes(B, H, W));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    char *p = (char *)ws;
+    float *gV = (float *)p; p += align_up(npix * 12, 256);
+    float *gN = (float *)p; p += align_up(npix * 12, 256);
+    int32_t *overflow = (int32_t *)p; p += 256;
+    int32_t *appended = (int32_t *)p; p += align_up((size_t)B * 4, 256);
+    void *cws = p;
+    GS_HIP(hipMemsetAsync(overflow, 0, 256 + align_up((size_t)B * 4, 256), st), name);
+    int rc;
+    if ((rc = gs_vertex_normal_maps(depth, intrinsics, poses, B, 1, H, W, nullptr, nullptr, gV, gN, stream))) return rc;
+    const int64_t HW = (int64_t)H * W;
+    for (int b = 0; b < B; ++b) {
+        const float *src[3] = {gV + b * HW * 3, gN + b * HW * 3, rgb + b * HW * 3};
+        float *dst[3] = {map_points + (size_t)b * Nmax * 3, map_normals + (size_t)b * Nmax * 3, map_colors + (size_t)b * Nmax * 3};
+        const int widths[3] = {3, 3, 3};
+        if ((rc = append_valid_pixels(3, depth + b * HW, HW, src, widths, dst, map_counts + b, Nmax, appended + b, overflow, cws, st)))
+            return rc;
+    }
+    if (stats) {
+        hipLaunchKernelGGL(fuse_stats_k, dim3(1), dim3(64), 0, st, overflow, overflow, overflow, (const float *)overflow, appended, B, stats);
         GS_LAUNCH_CHECK(name);
     }
     return GS_OK;

@@ -581,6 +581,20 @@ def pointfusion_update_raw(depth, rgb, K, poses, map_points, map_normals, map_co
          ptr(ws), ws.numel(), stream())
 
 
+def aggregate_update_raw(depth, rgb, K, poses, map_points, map_normals, map_colors, map_counts_i32, stats=None):
+    """One fused, sync-free ICPSLAM map update on arena arrays (reference slam/fusionutils.py:725-758 with
+    inplace=True): every valid live-frame pixel is appended, counts advance on the device."""
+    require_hip(depth, rgb, K, poses, map_points, map_normals, map_colors, map_counts_i32, op="aggregate_update")
+    for name, x in (("map_points", map_points), ("map_normals", map_normals), ("map_colors", map_colors), ("depth", depth), ("rgb", rgb)):
+        if not (x.is_contiguous() and x.dtype == torch.float32):
+            raise ValueError("aggregate_update: {} must be contiguous float32 (it is updated / read in place)".format(name))
+    B, H, W = depth.shape[:3]
+    K, poses = _f32c(K), _f32c(poses)
+    ws = workspace(ws_bytes("gs_aggregate_update_ws_bytes", B, H, W), depth.device, "aggregate_step")
+    call("gs_aggregate_update", ptr(depth), ptr(rgb), ptr(K), ptr(poses), B, H, W, ptr(map_points), ptr(map_normals),
+         ptr(map_colors), ptr(map_counts_i32), map_points.shape[1], ptr(stats), ptr(ws), ws.numel(), stream())
+
+
 # ---------------------------------------------------------------------------------------------- C / U / F / A
 def fusion_similar_raw(rows, n_rows_dev, max_rows, gV, gN, map_points, map_normals, dist_th, dot_th):
     """-> keep (max_rows,) uint8, max_dot (1,) float32 device."""

@@ -17,6 +17,73 @@ from .fusionutils import _project, update_map_aggregate
 __all__ = ["ICPSLAM"]
 
 
+class _MapArena:
+    """Device-resident map storage for the streamed sequence driver: capacity-doubling
+    (B, cap, C) arrays, per-sequence point counts that live on the device, O(1) append.  The host only tracks an
+    upper bound of the counts; it is tightened by asynchronous read-backs (pinned memory + events) that never
+    stall the frame loop."""
+
+    def __init__(self, B: int, hw: int, device, with_features: bool = True):
+        self.B, self.hw, self.device = B, hw, device
+        self.cap = 1 << max(2 * hw - 1, 1).bit_length()
+        mk = lambda c: torch.zeros((B, self.cap, c), dtype=torch.float32, device=device)
+        self.points, self.normals, self.colors = mk(3), mk(3), mk(3)
+        self.ccounts = mk(1) if with_features else None
+        self.counts = torch.zeros(B, dtype=torch.int32, device=device)
+        self.upper = 0          # host-side upper bound of max_b counts[b]
+        self.appends = 0        # frames appended so far
+        self._pinned = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._pending = []      # (appends at issue time, pinned buffer, event)
+
+    def _tighten(self):
+        while self._pending and self._pending[0][2].query():
+            at, buf, _ = self._pending.pop(0)
+            self._pinned.append(buf)
+            self.upper = min(self.upper, int(buf.max()) + (self.appends - at) * self.hw)
+
+    def reserve_frame(self) -> int:
+        """Make room for one more frame's worth of rows; returns the row bound to hand to the kernels."""
+        self._tighten()
+        need = self.upper + self.hw
+        if need > self.cap:
+            new_cap = 1 << (need - 1).bit_length()
+            for name in ("points", "normals", "colors", "ccounts"):
+                old = getattr(self, name)
+                if old is None:
+                    continue
+                new = torch.zeros((self.B, new_cap, old.shape[2]), dtype=torch.float32, device=self.device)
+                new[:, : self.cap] = old
+                setattr(self, name, new)
+            self.cap = new_cap
+        # one sequence: any row bound works as the "padded length" (rows beyond the count are zero); several
+        # sequences share the row stride, which is the capacity
+        return need if self.B == 1 else self.cap
+
+    def rows(self, bound: int):
+        """(points, normals, colors, ccounts) views of `bound` rows per sequence (contiguous)."""
+        if bound == self.cap:
+            return self.points, self.normals, self.colors, self.ccounts
+        cut = lambda x: None if x is None else x[:, :bound]
+        return cut(self.points), cut(self.normals), cut(self.colors), cut(self.ccounts)
+
+    def appended(self):
+        self.upper += self.hw
+        self.appends += 1
+        if self._pinned:
+            buf = self._pinned.pop()
+            buf.copy_(self.counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((self.appends, buf, ev))
+
+    def to_pointclouds(self) -> Pointclouds:
+        n = self.counts.tolist()  # the one host synchronisation of a streamed sequence
+        pick = lambda x: [x[b, : n[b]].clone() for b in range(self.B)]
+        return Pointclouds(points=pick(self.points), normals=pick(self.normals), colors=pick(self.colors),
+                           features=pick(self.ccounts) if self.ccounts is not None else None)
+
+
+
 class ICPSLAM(nn.Module):
     """Point-based SLAM with ICP odometry.  Keyword arguments, defaults, `forward` / `step` contract,
     warnings and errors follow the reference class."""
@@ -45,10 +112,18 @@ class ICPSLAM(nn.Module):
         device = torch.device(device) if device is not None else torch.device("cpu")
         self.device = torch.Tensor().to(device).device
 
+    # Whole sequences without gradients run on the arena-backed driver: two C calls per frame (localise, map
+    # update), map counts resident on the device, no host synchronisation until the map is handed back.  Same
+    # results as the step-by-step path (same kernels); `streamed = False` forces the latter.
+    streamed = True
+    _arena_features = False
+
     def forward(self, frames: RGBDImages):
         """frames (B, L, ...) -> (global map Pointclouds, recovered poses (B, L, 4, 4))."""
         if not isinstance(frames, RGBDImages):
             raise TypeError("Expected frames to be of type gradslam.RGBDImages. Got {0}.".format(type(frames)))
+        if self.streamed and self._can_stream(frames):
+            return self._forward_streamed(frames)
         pointclouds = Pointclouds(device=self.device)
         batch_size, seq_len = frames.shape[:2]
         recovered_poses = torch.empty(batch_size, seq_len, 4, 4).to(self.device)
@@ -62,6 +137,66 @@ class ICPSLAM(nn.Module):
             prev_frame = live_frame if self.odom != "gt" else None
             recovered_poses[:, s] = live_frame.poses[:, 0]
         return pointclouds, recovered_poses
+
+    def _can_stream(self, frames) -> bool:
+        # a subclass with a mapping step of its own keeps the step-by-step loop
+        if not getattr(type(self)._map, "_gs_arena_form", False):
+            return False
+        if frames.channels_first or self.device.type != "cuda":
+            return False
+        tensors = (frames.rgb_image, frames.depth_image, frames.intrinsics, frames.poses)
+        if frames.poses is None and self.odom == "gt":
+            return False  # the step-by-step path raises the reference's error for this
+        if any(t is not None and (not t.is_cuda or t.dtype != torch.float32) for t in tensors):
+            return False
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+            return False
+        return frames.shape[0] <= 60 and frames.shape[2] >= 2 and frames.shape[3] >= 2
+
+    def _arena_update(self, arena, depth_s, rgb_s, K, pose, bound, stats_row):
+        """update_map_aggregate on the arena (PointFusion overrides this with the fusion update)."""
+        from .. import ops
+
+        mp, mn, mc, _ = arena.rows(bound)
+        ops.aggregate_update_raw(depth_s, rgb_s, K, pose, mp, mn, mc, arena.counts, stats_row)
+
+    def _stream_warnings(self, s, row):
+        pass
+
+    def _forward_streamed(self, frames: RGBDImages):
+        from .. import ops
+
+        B, L, H, W = frames.shape
+        dev = frames.device
+        rgb, depth, K = frames.rgb_image.detach(), frames.depth_image.detach(), frames.intrinsics.detach().contiguous()
+        gt_poses = frames.poses.detach() if frames.poses is not None else None
+        arena = _MapArena(B, H * W, dev, with_features=self._arena_features)
+        recovered = torch.empty((B, L, 4, 4), dtype=torch.float32, device=dev)
+        stats = torch.zeros((L, 4 + B), dtype=torch.int32, device=dev)
+        p = self.odomprov
+        gparams = (p.lambda_max, p.B, p.B2, p.nu) if self.odom == "gradicp" else None
+        frame = lambda x, s: x[:, s].contiguous()  # (B,H,W,C); a view (no copy) for one contiguous sequence
+        prev, bound = None, None
+        for s in range(L):  # true serial dependence: pose s needs map s-1
+            d_s, c_s = frame(depth, s), frame(rgb, s)
+            if s == 0 or self.odom == "gt":
+                pose = (gt_poses[:, s:s + 1] if gt_poses is not None else
+                        torch.eye(4, dtype=torch.float32, device=dev).view(1, 1, 4, 4).repeat(B, 1, 1, 1))
+            else:
+                mp, mn, _, _ = arena.rows(bound)
+                pose, _, _ = ops.slam_localize_raw(d_s.unsqueeze(1), K, prev, mp, mn, arena.counts, self.dsratio, p.numiters,
+                                                   p.damp, p.dist_thresh, gparams)
+            bound = arena.reserve_frame()
+            self._arena_update(arena, d_s, c_s, K, pose, bound, stats[s])
+            arena.appended()
+            recovered[:, s] = pose[:, 0]
+            prev = pose
+        pointclouds = arena.to_pointclouds()
+        for s, row in enumerate(stats.tolist()):  # the reference's warnings, raised once the sequence is done
+            if row[2]:
+                raise RuntimeError("map arena overflow at frame {} (internal capacity bound violated)".format(s))
+            self._stream_warnings(s, row)
+        return pointclouds, recovered
 
     def step(self, pointclouds: Pointclouds, live_frame: RGBDImages, prev_frame: Optional[RGBDImages] = None,
              inplace: bool = False):
@@ -135,3 +270,5 @@ class ICPSLAM(nn.Module):
 
     def _map(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool = False):
         return update_map_aggregate(pointclouds, live_frame, inplace)
+
+    _map._gs_arena_form = True  # _arena_update above is this mapping step on arena storage

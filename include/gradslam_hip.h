@@ -287,6 +287,16 @@ int gs_pointfusion_update(const float *depth, const float *rgb, const float *int
                           float *map_ccounts, int32_t *map_counts, int Nmax, float dist_th, float dot_th,
                           float sigma, int32_t *stats, void *ws, size_t ws_bytes, gs_stream_t stream);
 
+/* The same for ICPSLAM's aggregate map (update_map_aggregate, slam/fusionutils.py:725-758 with inplace=True): the
+ * global vertices, normals and colours of every valid live-frame pixel are appended, unmerged, in (h, w) order
+ * behind the rows the arena holds; map_counts advances on the device.  stats (optional, 4 + B int32): [2] = overflow
+ * flag (set in all of 0..3 when rows had to be dropped), [4 + b] = rows appended. */
+size_t gs_aggregate_update_ws_bytes(int B, int H, int W);
+int gs_aggregate_update(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B,
+                        int H, int W, float *map_points, float *map_normals, float *map_colors,
+                        int32_t *map_counts, int Nmax, int32_t *stats, void *ws, size_t ws_bytes,
+                        gs_stream_t stream);
+
 /* ---------------------------------------------------------------- differentiable localisation step
  * gs_slam_localize with autograd (the same stages; gvertex = the live frame's global vertex map under the
  * PREVIOUS pose is an input here, so that its own adjoint chains into gs_vertex_normal_maps_backward).

@@ -672,8 +672,9 @@ def test_config5_shape_batch_independence_and_pose_gradients(gs):
         assert rel_err(a[1:2], s) < 1e-5, name
 
 
+@pytest.mark.parametrize("cls", ["PointFusion", "ICPSLAM"])
 @pytest.mark.parametrize("odom,B", [("icp", 1), ("gradicp", 2), ("gt", 2)])
-def test_streamed_arena_forward_equals_stepwise(gs, odom, B):
+def test_streamed_arena_forward_equals_stepwise(gs, odom, B, cls):
     """PointFusion.forward on the arena-backed driver (two C calls per frame, device-resident counts, one host
     sync per sequence) returns bit for bit what the step-by-step path returns, including when the arena has to
     grow (8 frames at 160x120 start from a 2*H*W-row arena)."""
@@ -683,14 +684,15 @@ def test_streamed_arena_forward_equals_stepwise(gs, odom, B):
     frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
     out = {}
     for streamed in (True, False):
-        slam = gs.slam.PointFusion(odom=odom, dsratio=2, numiters=6, device=DEV)
+        slam = getattr(gs.slam, cls)(odom=odom, dsratio=2, numiters=6, device=DEV)
         slam.streamed = streamed
         with torch.no_grad():
             out[streamed] = slam(frames)
     (pa, qa), (pb, qb) = out[True], out[False]
     assert torch.equal(qa, qb)
     assert pa.num_points_per_pointcloud.tolist() == pb.num_points_per_pointcloud.tolist()
-    for attr in ("points_list", "normals_list", "colors_list", "features_list"):
+    assert pa.has_features == pb.has_features == (cls == "PointFusion")
+    for attr in ("points_list", "normals_list", "colors_list") + (("features_list",) if cls == "PointFusion" else ()):
         for b in range(B):
             assert torch.equal(getattr(pa, attr)[b], getattr(pb, attr)[b]), (attr, b)
     # padded views keep the zero-padding contract
