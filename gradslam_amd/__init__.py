@@ -13,4 +13,5 @@ CPU or PyTorch fallback (importing works anywhere; computing raises without the 
 __version__ = "0.1.0"
 
 from . import geometry, odometry, slam, structures  # noqa: F401,E402
+from .geometry.projutils import *  # noqa: F401,F403,E402  (reference __init__.py:6)
 from .structures import Pointclouds, RGBDImages  # noqa: F401,E402
