@@ -349,3 +349,124 @@ def test_inverse_intrinsics(lastdim):
     for bad in (torch.rand(3), torch.rand(3, 4), torch.rand(5, 5)):
         with pytest.raises(ValueError):
             gsm.inverse_intrinsics(bad)
+
+
+# ------------------------------------------------------------------ structures/test_pointclouds.py (container algebra, CPU)
+def _ragged3():
+    return [torch.tensor([[0.1, 0.3, 0.5], [0.5, 0.2, 0.1], [0.6, 0.8, 0.7]]),
+            torch.tensor([[0.1, 0.3, 0.3], [0.6, 0.7, 0.8], [0.2, 0.3, 0.4], [0.1, 0.5, 0.3]]),
+            torch.tensor([[0.7, 0.3, 0.6], [0.2, 0.4, 0.8], [0.9, 0.5, 0.2], [0.2, 0.3, 0.4], [0.9, 0.3, 0.8]])]
+
+
+def _expect(pc, want_list):
+    for got, want in zip(pc.points_list, want_list):
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    for b, want in enumerate(want_list):
+        n = want.shape[0]
+        torch.testing.assert_close(pc.points_padded[b, :n], want, rtol=1e-5, atol=1e-6)
+        assert bool((pc.points_padded[b, n:] == 0).all())  # padding stays zero under every op
+
+
+def test_pointclouds_arithmetic_operators():
+    """structures/test_pointclouds.py:153-269: scalar, (1,1,3) and (B,1,3) operands; results own their storage."""
+    import gradslam_amd as gsm
+
+    pts = _ragged3()
+    pc = gsm.Pointclouds([p.clone() for p in pts])
+    pc.offset_(5)
+    _expect(pc, [p + 5 for p in pts])
+    pc = gsm.Pointclouds([p.clone() for p in pts])
+    _expect(pc + 5, [p + 5 for p in pts])
+    a = torch.tensor([2.0, 5.0, 7.0]).reshape(1, 1, 3)
+    _expect(pc + a, [p + a.squeeze() for p in pts])
+    per_b = torch.tensor([[0.0, 1.0, -4.0], [-2.0, 10.0, -0.2], [1.0, 5.0, 3.0]]).unsqueeze(1)
+    res = pc + per_b
+    _expect(res, [p + per_b[b] for b, p in enumerate(pts)])
+    pc.scale_(5)
+    _expect(pc, [p * 5 for p in pts])
+    assert res.points_padded.data_ptr() != pc.points_padded.data_ptr()
+    pc = gsm.Pointclouds([p.clone() for p in pts])
+    _expect(pc * a, [p * a.squeeze() for p in pts])
+    _expect(pc - a, [p - a.squeeze() for p in pts])
+    _expect((pc * -1) + a, [a.squeeze() - p for p in pts])
+    _expect(pc / a, [p / a.squeeze() for p in pts])
+    _expect(pc, pts)  # the out-of-place operators left the operand alone
+
+
+def test_pointclouds_rigid_and_projective_ops():
+    """structures/test_pointclouds.py:271-455: rotate / transform (single and per-cloud matrices, pre and post
+    multiplication, normals rotate with the points) and pinhole projection (single and per-cloud intrinsics)."""
+    import gradslam_amd as gsm
+
+    pts = _ragged3()
+    T = torch.tensor([[-0.802837, 0.056561, -0.593509, 2.583219], [0.596192, 0.071654, -0.799638, 4.008804],
+                      [-0.002701, -0.995825, -0.091248, 1.439254], [0.0, 0.0, 0.0, 1.0]])
+    R, tv = T[:3, :3], T[:3, 3]
+    new = lambda: gsm.Pointclouds([p.clone() for p in pts])  # noqa: E731
+    pre = [p @ R.t() for p in pts]
+    _expect(new().rotate_(R), pre)
+    both = gsm.Pointclouds([p.clone() for p in pts], [p * 2 for p in pts]).rotate(R)
+    _expect(both, pre)
+    for got, p in zip(both.normals_list, pts):
+        torch.testing.assert_close(got, (p * 2) @ R.t(), rtol=1e-5, atol=1e-6)
+    post = [p @ R for p in pts]
+    _expect(new().rotate_(R, pre_multiplication=False), post)
+    _expect(new() @ R, post)
+    Rb = torch.stack([R * i for i in (1, 2, 3)])
+    pre_b = [p @ Rb[b].t() for b, p in enumerate(pts)]
+    _expect(new().rotate_(Rb), pre_b)
+    _expect(new().rotate(Rb), pre_b)
+    _expect(new().transform_(T), [p + tv for p in pre])
+    _expect(new().transform(T), [p + tv for p in pre])
+    Tb = torch.stack([T * i for i in (1, 2, 3)])
+    moved_b = [p + tv * (b + 1) for b, p in enumerate(pre_b)]
+    _expect(new().transform_(Tb), moved_b)
+    _expect(new().transform(Tb), moved_b)
+
+    def K(f, cx, cy):
+        return torch.tensor([[f, 0.0, cx, 0.0], [0.0, f, cy, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+
+    Ks = [K(577.87, 319.5, 239.5), K(377.87, 219.5, 139.5), K(677.87, 419.5, 339.5)]
+    singles = [new().pinhole_projection_(k) for k in Ks]
+    for s, k in zip(singles, Ks):
+        assert s.points_padded.shape == (3, 5, 3) and s.num_points_per_pointcloud.tolist() == [3, 4, 5]
+        _expect(s, [torch.stack([k[0, 0] * p[:, 0] / p[:, 2] + k[0, 2], k[1, 1] * p[:, 1] / p[:, 2] + k[1, 2],
+                                 torch.ones(len(p))], -1) for p in pts])
+    batched = new().pinhole_projection_(torch.stack(Ks))
+    for b in range(3):
+        torch.testing.assert_close(batched.points_padded[b], singles[b].points_padded[b])
+    for bad in (torch.eye(3)[None], torch.rand(2, 3, 3), "R"):
+        with pytest.raises((TypeError, ValueError)):
+            new().rotate_(bad)
+
+
+def test_pointclouds_clone_detach_index_append_empty():
+    """structures/test_pointclouds.py:729-1042, :1266-1300: clone / detach semantics, every index form, append
+    onto ragged and empty containers."""
+    import gradslam_amd as gsm
+
+    pts = [p.clone().requires_grad_(True) for p in _ragged3()]
+    pc = gsm.Pointclouds(pts, [p * 2 for p in pts], [p * 3 for p in pts], [p[:, :1] for p in pts])
+    c = pc.clone()
+    assert c.points_padded.requires_grad and c.points_padded.data_ptr() != pc.points_padded.data_ptr()
+    torch.testing.assert_close(c.colors_padded, pc.colors_padded)
+    dt = pc.detach()
+    assert not dt.points_padded.requires_grad and not dt.features_list[0].requires_grad
+    for index, want in ((1, [1]), (slice(0, 2), [0, 1]), ([2, 0], [2, 0]), (torch.tensor([0, 2]), [0, 2]),
+                        (torch.tensor([False, True, True]), [1, 2])):
+        sub = pc[index]
+        assert len(sub) == len(want)
+        for got, b in zip(sub.normals_list, want):
+            torch.testing.assert_close(got, pts[b] * 2)
+    with pytest.raises(IndexError):
+        pc[3.5]
+    grown = pc.detach().clone()
+    grown.append_points(pc.detach())
+    assert grown.num_points_per_pointcloud.tolist() == [6, 8, 10]
+    for b in range(3):
+        torch.testing.assert_close(grown.points_list[b], torch.cat([pts[b], pts[b]]).detach())
+        torch.testing.assert_close(grown.features_list[b], torch.cat([pts[b][:, :1]] * 2).detach())
+    empty = gsm.Pointclouds()
+    assert len(empty) == 0 and not empty.has_points and empty.points_list is None and empty.points_padded is None
+    empty.append_points(pc.detach())
+    assert empty.num_points_per_pointcloud.tolist() == [3, 4, 5] and empty.has_normals and empty.has_colors
