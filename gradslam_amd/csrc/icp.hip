@@ -412,7 +412,9 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
     }
     GS_STAMP(2);
     GS_COUNT(4, (unsigned long long)n_scanned);
-    GS_COUNT(5, (unsigned long long)sh.cnt);
+    // diagnostic build: survivors of the last round | HW_ID << 16 | XCC_ID << 48 (which CU the block ran on)
+    GS_COUNT(5, (unsigned long long)sh.cnt | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
+                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 48));
     (void)n_scanned;
     GS_STAMP(3);
     return ok ? sh.key[lane] : KEY_NONE;

@@ -724,12 +724,13 @@ def test_short_loops_match_the_per_op_formulation(gs, golden, grad_lm):
             assert torch.equal(ia, ib) and torch.equal(ia, ic), numiters
 
 
-@pytest.mark.parametrize("kind", ["sorted", "random", "clustered"])
-def test_knn_large_target_equals_bruteforce(gs, kind):
-    """200 k targets (several rounds of the LDS survivor list per tile): the pruned search must stay the brute-force
-    scan's, bit for bit, whether the boxes prune a lot (sorted / clustered clouds) or nothing (random)."""
+@pytest.mark.parametrize("kind,ns,nt", [("sorted", 6000, 200037), ("random", 6000, 200037), ("clustered", 6000, 200037),
+                                        ("sorted", 1500, 1300011), ("clustered", 1500, 1300011)])
+def test_knn_large_target_equals_bruteforce(gs, kind, ns, nt):
+    """200 k targets (two-level boxes, several survivor rounds per tile) and 1.3 M targets (more super-boxes than one
+    first-level round holds): the pruned search must stay the brute-force scan's, bit for bit, whether the boxes
+    prune a lot (sorted / clustered clouds) or nothing (random)."""
     torch.manual_seed(5)
-    ns, nt = 6000, 200000 + 37
     src, tgt = torch.randn(ns, 3, device=DEV), torch.randn(nt, 3, device=DEV)
     if kind == "sorted":
         tgt = tgt[tgt[:, 0].argsort()].contiguous()

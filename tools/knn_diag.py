@@ -36,7 +36,7 @@ for it in range(3):
 def report(title):
     global a
     print("====", title)
-    a = dbg.cpu().numpy().reshape(nblk, 16, 8).astype(np.float64)
+    a = (dbg.cpu().numpy().reshape(nblk, 16, 8) & np.array([-1, -1, -1, -1, -1, 0xffff, -1, -1], dtype=np.int64)).astype(np.float64)
     tick = 1e-2
     t0, t1, t2, t3, ns = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 4]
     g0 = t0.min()
@@ -53,7 +53,7 @@ dbg.zero_()
 T, _, _ = ops.icp_device_loop(src, tgt, nrm, torch.eye(4, device=dev), 10, 1e-8, None)
 torch.cuda.synchronize()
 report("last association of a 10-iteration ICP loop (seeded by the previous neighbour)")
-a = dbg.cpu().numpy().reshape(nblk, 16, 8).astype(np.float64)
+a = (dbg.cpu().numpy().reshape(nblk, 16, 8) & np.array([-1, -1, -1, -1, -1, 0xffff, -1, -1], dtype=np.int64)).astype(np.float64)
 t6, t7, t0, t3 = a[..., 6], a[..., 7], a[..., 0], a[..., 3]
 print("folded step (prologue) us per wave: p50 %.2f p99 %.2f ; prologue end -> search start p50 %.2f ; search p50 %.2f ; kernel entry spread p99 %.2f" % (
     *np.percentile((t7 - t6) * 0.01, [50, 99]), np.percentile((t0 - t7) * 0.01, 50), np.percentile((t3 - t0) * 0.01, 50),
@@ -70,7 +70,7 @@ torch.cuda.synchronize()
 st = dbg3[:8].cpu().numpy().astype(np.float64)
 print("==== last icp_step_k (us): copy-in+reduce %.2f | decide %.2f | solve6 %.2f | rest(exp, out) %.2f | total %.2f" % (
     (st[1] - st[0]) * 0.01, (st[3] - st[1]) * 0.01, (st[4] - st[3]) * 0.01, (st[2] - st[4]) * 0.01, (st[2] - st[0]) * 0.01))
-a = dbg.cpu().numpy().reshape(nblk, 16, 8).astype(np.float64)
+a = (dbg.cpu().numpy().reshape(nblk, 16, 8) & np.array([-1, -1, -1, -1, -1, 0xffff, -1, -1], dtype=np.int64)).astype(np.float64)
 tick = 1e-2  # wall_clock64: 100 MHz -> 10 ns per tick = 0.01 us
 t0, t1, t2, t3, ns = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 4]
 g0 = t0.min()

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Diagnostic only: phase stamps of the LAST association launch of a long streamed PointFusion run, i.e. with
+the ICP target grown to the downsampled active map (needs make -C gradslam_amd/csrc diag)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gradslam_amd import _native
+_native.LIB_PATH = os.path.join(ROOT, "gradslam_amd", "libgradslam_hip_diag.so")
+import gradslam_amd as gs
+from gradslam_amd.synthetic import make_sequence
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+dev = "cuda:0"
+c, d, K, P = make_sequence(1, n, 480, 640, seed=100)
+frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
+lib = _native.lib()
+lib.gs_diag_set_buffer.argtypes = [ctypes.c_void_p]
+nblk = 300
+dbg = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
+assert lib.gs_diag_set_buffer(dbg.data_ptr()) == 0
+slam = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10, device=dev)
+with torch.no_grad():
+    pcs, poses = slam(frames)
+torch.cuda.synchronize()
+print("frames", n, "map", int(pcs.num_points_per_pointcloud.item()))
+raw = dbg.cpu().numpy().reshape(nblk, 16, 8)
+a = raw.astype(np.float64)
+live = a[..., 3].max(1) > 0
+a = a[live]
+place = raw[live][:, 0, 5]          # wave 0's slot 5: survivors | HW_ID << 16 | XCC_ID << 48
+hw, xcc = (place >> 16) & 0xffffffff, (place >> 48) & 0xf
+cu, sh_, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 0x7
+where = xcc * 4096 + se * 256 + sh_ * 16 + cu
+a[..., 5] = (raw[live][..., 5] & 0xffff)
+print("blocks with stamps", int(live.sum()))
+tick = 1e-2
+t0, t1, t2, t3, ns, t6, t7 = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 4], a[..., 6], a[..., 7]
+pc = lambda x, q: tuple(np.percentile(x, q))
+print("prologue (folded step) us per wave p50 %.2f p99 %.2f" % pc((t7 - t6) * tick, [50, 99]))
+print("prologue end -> search start p50 %.2f" % np.percentile((t0 - t7) * tick, 50))
+print("seed phase us  (per wave)  p50 %.2f p99 %.2f" % pc((t1 - t0) * tick, [50, 99]))
+print("main loop us   (per wave)  p50 %.2f p99 %.2f max %.2f" % pc((t2 - t1) * tick, [50, 99, 100]))
+print("barrier wait us(per wave)  p50 %.2f p99 %.2f" % pc((t3 - t2) * tick, [50, 99]))
+print("block total us             p50 %.2f p99 %.2f max %.2f" % pc((t3.max(1) - t6.min(1)) * tick, [50, 99, 100]))
+print("kernel entry spread us p50 %.2f p99 %.2f" % pc((t6.min(1) - t6.min()) * tick, [50, 99]))
+print("kernel span us %.1f" % ((t3.max() - t6.min()) * tick))
+print("chunks scanned per block: mean %.1f max %d ; coarse survivors per block mean %.1f max %d" % (
+    ns.sum(1).mean(), ns.sum(1).max(), a[..., 5].max(1).mean(), a[..., 5].max(1).max()))
+ml = ((t2 - t1) * tick).max(1)
+order = np.argsort(-ml)
+print("slowest blocks: (main loop us, coarse survivors of the last round, chunks scanned)")
+for b in order[:12]:
+    print("   %.1f us  survivors %d  scanned %d" % (ml[b], a[b, :, 5].max(), ns[b].sum()))
+print("median blocks:")
+for b in order[len(order) // 2 - 3: len(order) // 2 + 3]:
+    print("   %.1f us  survivors %d  scanned %d" % (ml[b], a[b, :, 5].max(), ns[b].sum()))
+print("corr(main loop, survivors) %.2f  corr(main loop, scanned) %.2f" % (np.corrcoef(ml, a[..., 5].max(1))[0, 1], np.corrcoef(ml, ns.sum(1))[0, 1]))
+
+uniq, counts = np.unique(where, return_counts=True)
+print("distinct CUs used %d ; blocks per CU histogram %s" % (len(uniq), dict(zip(*np.unique(counts, return_counts=True)))))
+per_cu = dict(zip(uniq, counts))
+share = np.array([per_cu[w] for w in where])
+for k in sorted(set(share)):
+    print("  blocks on a CU hosting %d block(s): n=%d main loop p50 %.1f us max %.1f us" % (k, (share == k).sum(), np.percentile(ml[share == k], 50), ml[share == k].max()))
+print("blocks per XCC:", dict(zip(*np.unique(xcc, return_counts=True))))
