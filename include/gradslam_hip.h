@@ -229,6 +229,7 @@ typedef struct gs_icp_hints {
     int32_t grid_w, grid_h;
 } gs_icp_hints;
 
+/* point_to_plane_ICP (odometry/icputils.py:310-367) as one call on the device (section comment above). */
 size_t gs_icp_ws_bytes(int max_ns, int max_nt);
 int gs_icp_point_to_plane(const float *src, const int32_t *d_ns, int max_ns, const float *tgt,
                           const float *tgt_normals, const int32_t *d_nt, int max_nt,
@@ -320,15 +321,6 @@ int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int 
                               float *grad_gvertex, float *grad_map_points, float *grad_map_normals,
                               float *grad_prev_poses, void *ws, size_t ws_bytes, gs_stream_t stream);
 
-/* ---------------------------------------------------------------- whole localisation step
- * ICPSLAM._localize for odom in {icp, gradicp} (slam/icpslam.py:238-247) as ONE call with no host
- * synchronisation: live-frame maps posed with the previous pose (rgbdimages.py:643-762), ds-grid
- * source cloud (icputils.py:651-669), active map points on the ds-grid of the previous frame
- * (fusionutils.py:247-282 + icputils.py:596-619), the (grad)ICP loop, and the pose composition
- * T . prev_pose (kornia compose_transformations semantics).  depth (B,H,W) is ONE frame per batch
- * element; prev_poses / out_poses are B x 16.  vertex / normal / gnormal (B,H,W,3) are optional outputs
- * (NULL to skip), gvertex is required scratch/output.  use_grad_lm selects the gradLM variant. */
-int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream);
 /* gs_slam_localize can replay its ICP loops as a cached hipGraph once a configuration repeats (all loop
  * arguments live in the caller's workspace).  mode: 1 on, 0 off (eager launches), -1 automatic: the library
  * times its own eager launches on the host and switches to graph replay only on hosts where a launch costs
@@ -337,6 +329,16 @@ void gs_set_graph_mode(int mode);
 /* Diagnostics of that policy: out4 = {eager enqueues timed, their minimum host cost per launch in us, graphs
  * captured, graph replays}. */
 int gs_graph_stats(double *out4);
+/* out = T . P for B pairs of 4x4 (compose_transformations as slam/icpslam.py:245-247 uses it). */
+int gs_compose_poses(const float *T, const float *P, int B, float *out, gs_stream_t stream);
+/* ---------------------------------------------------------------- whole localisation step
+ * ICPSLAM._localize for odom in {icp, gradicp} (slam/icpslam.py:238-247) as ONE call with no host
+ * synchronisation: live-frame maps posed with the previous pose (rgbdimages.py:643-762), ds-grid
+ * source cloud (icputils.py:651-669), active map points on the ds-grid of the previous frame
+ * (fusionutils.py:247-282 + icputils.py:596-619), the (grad)ICP loop, and the pose composition
+ * T . prev_pose (kornia compose_transformations semantics).  depth (B,H,W) is ONE frame per batch
+ * element; prev_poses / out_poses are B x 16.  vertex / normal / gnormal (B,H,W,3) are optional outputs
+ * (NULL to skip), gvertex is required scratch/output.  use_grad_lm selects the gradLM variant. */
 size_t gs_slam_localize_ws_bytes(int B, int H, int W, int ds, int Nmax);
 int gs_slam_localize(const float *depth, const float *intrinsics, const float *prev_poses, int B,
                      int H, int W, int ds, const float *map_points, const float *map_normals,

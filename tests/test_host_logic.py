@@ -32,6 +32,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.gs_abi_version() == 1
 
 
+def test_integration_notes_cover_every_entry_point():
+    """INTEGRATION.md (the reference-side binding notes) names every symbol the header declares."""
+    notes = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    header = open(os.path.join(REPO, "include", "gradslam_hip.h")).read()
+    declared = set(re.findall(r"\b(gs_[a-z0-9_]+)\(", header))
+    assert declared and not [n for n in sorted(declared) if n not in notes]
+
+
 def test_abi_is_plain_c():
     text = open(os.path.join(REPO, "include", "gradslam_hip.h")).read()
     code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
