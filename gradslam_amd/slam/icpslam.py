@@ -35,6 +35,28 @@ class _MapArena:
         self._pinned = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(4)]
         self._pending = []      # (appends at issue time, pinned buffer, event)
 
+    @classmethod
+    def for_one_step(cls, pointclouds: Pointclouds, B: int, hw: int, device, with_features: bool):
+        """Arena holding a copy of `pointclouds` with room for exactly one more frame (the step-by-step API)."""
+        self = cls.__new__(cls)
+        self.B, self.hw, self.device = B, hw, device
+        n_old = max(pointclouds._counts) if pointclouds.has_points else 0
+        self.cap = n_old + hw
+        mk = lambda c: torch.zeros((B, self.cap, c), dtype=torch.float32, device=device)
+        self.points, self.normals, self.colors = mk(3), mk(3), mk(3)
+        self.ccounts = mk(1) if with_features else None
+        if pointclouds.has_points:
+            self.points[:, :n_old] = pointclouds.points_padded
+            self.normals[:, :n_old] = pointclouds.normals_padded
+            self.colors[:, :n_old] = pointclouds.colors_padded
+            if with_features:
+                self.ccounts[:, :n_old] = pointclouds.features_padded
+            self.counts = pointclouds._counts_i32().clone()
+        else:
+            self.counts = torch.zeros(B, dtype=torch.int32, device=device)
+        self.upper, self.appends, self._pinned, self._pending = n_old, 0, [], []
+        return self
+
     def _tighten(self):
         while self._pending and self._pending[0][2].query():
             at, buf, _ = self._pending.pop(0)
@@ -116,6 +138,7 @@ class ICPSLAM(nn.Module):
     # update), map counts resident on the device, no host synchronisation until the map is handed back.  Same
     # results as the step-by-step path (same kernels); `streamed = False` forces the latter.
     streamed = True
+    fused_map = True   # step(): the mapping step as one fused call when nothing needs gradients (False = staged)
     _arena_features = False
 
     def forward(self, frames: RGBDImages):
@@ -268,7 +291,53 @@ class ICPSLAM(nn.Module):
         live_frame._global_vertex_map = live_frame._global_normal_map = None
         return poses
 
+    def _map_on_arena(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool):
+        """The mapping step as ONE fused call + ONE host read (counts and warning counters together) when nothing
+        needs gradients and the arguments are well formed; None = take the staged path (which also raises the
+        reference's errors for malformed arguments).  Same kernels, same results as the staged path."""
+        if not (isinstance(pointclouds, Pointclouds) and isinstance(live_frame, RGBDImages)):
+            return None
+        if live_frame.channels_first or live_frame.shape[1] != 1 or live_frame.poses is None:
+            return None
+        B, _, H, W = live_frame.shape
+        tensors = (live_frame.rgb_image, live_frame.depth_image, live_frame.intrinsics, live_frame.poses)
+        if any(not t.is_cuda or t.dtype != torch.float32 for t in tensors) or B > 60 or H < 2 or W < 2:
+            return None
+        dev = live_frame.depth_image.device
+        feats = self._arena_features
+        if pointclouds.has_points:
+            if (len(pointclouds) != B or pointclouds.device != dev or not pointclouds.has_normals or not pointclouds.has_colors
+                    or pointclouds.has_features != feats or (feats and pointclouds.num_features != 1)):
+                return None
+            held = (pointclouds.points_padded, pointclouds.normals_padded, pointclouds.colors_padded)
+        else:
+            if pointclouds.device != dev:
+                return None
+            held = ()
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors + held):
+            return None
+        had = pointclouds.has_points
+        n_old = list(pointclouds._counts) if had else [0] * B
+        arena = _MapArena.for_one_step(pointclouds, B, H * W, dev, feats)
+        stats = torch.zeros(4 + B, dtype=torch.int32, device=dev)
+        self._arena_update(arena, live_frame.depth_image[:, 0].contiguous(), live_frame.rgb_image[:, 0].contiguous(),
+                           live_frame.intrinsics.contiguous(), live_frame.poses, arena.cap, stats)
+        host = torch.cat([arena.counts, stats]).tolist()  # the one host synchronisation of the step
+        n_new, row = host[:B], host[B:]
+        if row[2]:
+            raise RuntimeError("map arena overflow (internal capacity bound violated)")
+        if had:
+            self._stream_warnings(1, row)
+        arrays = (arena.points, arena.normals, arena.colors, arena.ccounts)
+        if inplace:
+            return pointclouds._adopt_rows(arrays, n_new)
+        if had:  # like the reference, the merged rows also land in the object that was passed in
+            cut = max(n_old)
+            pointclouds._adopt_rows(tuple(None if x is None else x[:, :cut].clone() for x in arrays), n_old)
+        return Pointclouds(device=dev)._adopt_rows(arrays, n_new)
+
     def _map(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool = False):
-        return update_map_aggregate(pointclouds, live_frame, inplace)
+        fused = self._map_on_arena(pointclouds, live_frame, inplace) if self.fused_map else None
+        return fused if fused is not None else update_map_aggregate(pointclouds, live_frame, inplace)
 
     _map._gs_arena_form = True  # _arena_update above is this mapping step on arena storage

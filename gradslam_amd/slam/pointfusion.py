@@ -36,6 +36,9 @@ class PointFusion(ICPSLAM):
         self.sigma = sigma
 
     def _map(self, pointclouds: Pointclouds, live_frame: RGBDImages, inplace: bool = False):
+        fused = self._map_on_arena(pointclouds, live_frame, inplace) if self.fused_map else None
+        if fused is not None:
+            return fused
         return update_map_fusion(pointclouds, live_frame, self.dist_th, self.dot_th, self.sigma, inplace)
 
     _map._gs_arena_form = True  # _arena_update below is this mapping step on arena storage

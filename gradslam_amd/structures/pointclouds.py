@@ -262,6 +262,18 @@ class Pointclouds(object):
         self._colors_padded, self._features_padded = colors, features
         self._points_list = self._normals_list = self._colors_list = self._features_list = None
 
+    def _adopt_rows(self, arrays, counts: List[int]):
+        """Become the clouds held in arena arrays: arrays = (points, normals, colors, features-or-None), each
+        (B, cap, C) with rows beyond counts[b] zero.  The list items are views of the arrays (no copy)."""
+        self._B = int(arrays[0].shape[0])
+        self.device = arrays[0].device
+        for a, arr in zip(_ATTRS, arrays):
+            setattr(self, "_%s_list" % a, None if arr is None else [arr[b, : counts[b]] for b in range(self._B)])
+            setattr(self, "_%s_padded" % a, None)
+            setattr(self, "_has_%s" % a, arr is not None)
+        self._set_counts(counts)
+        return self
+
     # ------------------------------------------------------------------ indexing
     def __getitem__(self, index):
         if not self.has_points:

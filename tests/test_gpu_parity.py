@@ -683,20 +683,48 @@ def test_streamed_arena_forward_equals_stepwise(gs, odom, B, cls):
     c, dd, K, P = make_sequence(B, 8, 120, 160, seed=21)
     frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
     out = {}
-    for streamed in (True, False):
+    # streamed sequence driver / step() with the one-call mapping step / step() with the staged mapping step
+    for mode, (streamed, fused_map) in {"arena": (True, True), "step": (False, True), "staged": (False, False)}.items():
         slam = getattr(gs.slam, cls)(odom=odom, dsratio=2, numiters=6, device=DEV)
-        slam.streamed = streamed
+        slam.streamed, slam.fused_map = streamed, fused_map
         with torch.no_grad():
-            out[streamed] = slam(frames)
-    (pa, qa), (pb, qb) = out[True], out[False]
-    assert torch.equal(qa, qb)
-    assert pa.num_points_per_pointcloud.tolist() == pb.num_points_per_pointcloud.tolist()
-    assert pa.has_features == pb.has_features == (cls == "PointFusion")
-    for attr in ("points_list", "normals_list", "colors_list") + (("features_list",) if cls == "PointFusion" else ()):
-        for b in range(B):
-            assert torch.equal(getattr(pa, attr)[b], getattr(pb, attr)[b]), (attr, b)
-    # padded views keep the zero-padding contract
-    assert torch.equal(pa.points_padded, pb.points_padded)
+            out[mode] = slam(frames)
+    pb, qb = out["staged"]
+    for mode in ("arena", "step"):
+        pa, qa = out[mode]
+        assert torch.equal(qa, qb), mode
+        assert pa.num_points_per_pointcloud.tolist() == pb.num_points_per_pointcloud.tolist(), mode
+        assert pa.has_features == pb.has_features == (cls == "PointFusion")
+        for attr in ("points_list", "normals_list", "colors_list") + (("features_list",) if cls == "PointFusion" else ()):
+            for b in range(B):
+                assert torch.equal(getattr(pa, attr)[b], getattr(pb, attr)[b]), (mode, attr, b)
+        # padded views keep the zero-padding contract
+        assert torch.equal(pa.points_padded, pb.points_padded), mode
+
+
+@pytest.mark.parametrize("cls", ["PointFusion", "ICPSLAM"])
+def test_step_out_of_place_leaves_a_separate_map(gs, cls):
+    """step(..., inplace=False) on the one-call mapping step: the returned map is the staged path's, the map that
+    was passed in keeps its own storage and length (and, like the reference's, now holds the merged rows)."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(1, 3, 120, 160, seed=4)
+    frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
+    res = {}
+    for fused_map in (True, False):
+        slam = getattr(gs.slam, cls)(odom="gt", device=DEV)
+        slam.fused_map = fused_map
+        with torch.no_grad():
+            m0, _ = slam.step(gs.Pointclouds(device=DEV), frames[:, 0], None)
+            n0 = m0.num_points_per_pointcloud.tolist()
+            m1, _ = slam.step(m0, frames[:, 1], None, inplace=False)
+        assert m0.num_points_per_pointcloud.tolist() == n0 and m1 is not m0
+        assert m1.points_padded.data_ptr() != m0.points_padded.data_ptr()
+        assert int(m1.num_points_per_pointcloud[0]) > n0[0]
+        res[fused_map] = (m0, m1)
+    for a, b in zip(res[True], res[False]):
+        for attr in ("points_list", "normals_list", "colors_list") + (("features_list",) if cls == "PointFusion" else ()):
+            assert torch.equal(getattr(a, attr)[0], getattr(b, attr)[0]), attr
 
 
 @pytest.mark.parametrize("grad_lm", [False, True], ids=["LM", "gradLM"])

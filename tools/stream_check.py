@@ -17,6 +17,7 @@ res = {}
 for streamed in (True, False, True, False):
     slam = gs.slam.PointFusion(odom=odom, dsratio=4, numiters=10, device=dev)
     slam.streamed = streamed
+    slam.fused_map = False  # the staged mapping step: the independent formulation
     with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pcs, poses = slam(frames)
