@@ -23,7 +23,7 @@ with torch.no_grad():
     tgt = gs.odometry.icputils._gather_by_table(pcs, rows[: int(cnt.item())], 1).points_list[0].contiguous()
 print("src", src.shape, "tgt", tgt.shape)
 lib = _native.lib()
-nblk = (src.shape[0] + 63) // 64
+nblk = 2048  # >= the association's grid for any cloud these diagnostics use (mixed 64 / 16-point tiling)
 dbg = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
 lib.gs_diag_set_buffer.argtypes = [ctypes.c_void_p]
 for it in range(3):

@@ -16,7 +16,7 @@ c, d, K, P = make_sequence(1, n, 480, 640, seed=100)
 frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
 lib = _native.lib()
 lib.gs_diag_set_buffer.argtypes = [ctypes.c_void_p]
-nblk = 300
+nblk = 2048  # >= the association's grid (mixed 64 / 16-point tiling: 432 blocks at 19 200 candidates)
 dbg = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
 assert lib.gs_diag_set_buffer(dbg.data_ptr()) == 0
 slam = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10, device=dev)
