@@ -859,3 +859,34 @@ def test_arena_entry_points_against_torch(gs):
         else:  # no correspondence: untouched (fuse_with_map skips the merge), whereas the formula would re-round every point
             for x, y in zip(got, (mp, mn, mc, cc)):
                 assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("H,W,ds,B", [(50, 70, 3, 1), (33, 65, 2, 2), (17, 19, 1, 1), (121, 67, 5, 2)])
+def test_odd_image_shapes_vs_oracle(gs, H, W, ds, B):
+    """Image sizes that are no multiple of any tile (64x4 map tiles, 64-point ICP tiles, 256-row compaction blocks)
+    and ds ratios that do not divide them: the ground-truth-odometry map must be the oracle's (same counts, same
+    attributes), ICP localisation must agree with it to the path's tolerance, on all three drivers."""
+    from gradslam_amd.synthetic import make_sequence
+    from oracle import slam as oslam
+
+    c, dd, K, P = make_sequence(B, 3, H, W, seed=H + W, band=2)
+    frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
+    ocloud, oposes = oslam.run(c, dd, K, P, mode="pointfusion", odom="gt", dsratio=ds, numiters=5)
+    for streamed, fused_map in ((True, True), (False, True), (False, False)):
+        slam = gs.slam.PointFusion(odom="gt", dsratio=ds, numiters=5, device=DEV)
+        slam.streamed, slam.fused_map = streamed, fused_map
+        with torch.no_grad():
+            pcs, poses = slam(frames)
+        assert pcs.num_points_per_pointcloud.tolist() == list(ocloud.counts)
+        for mine, theirs in ((pcs.points_list, ocloud.points), (pcs.normals_list, ocloud.normals),
+                             (pcs.colors_list, ocloud.colors), (pcs.features_list, ocloud.feats)):
+            for b in range(B):
+                a, r = mine[b].cpu().double(), theirs[b].double()
+                assert ((a - r).abs().amax(1) > 1e-5 * r.abs().max()).float().mean().item() < 2e-3
+    # ICP on the same odd grids: a few hundred source points, fewer than one 64-point tile per wave in places
+    _, oposes = oslam.run(c, dd, K, P, mode="pointfusion", odom="icp", dsratio=ds, numiters=5)
+    slam = gs.slam.PointFusion(odom="icp", dsratio=ds, numiters=5, device=DEV)
+    with torch.no_grad():
+        pcs, poses = slam(frames)
+    assert torch.isfinite(poses).all()
+    assert rel_err(poses.cpu(), oposes) < 5e-3  # small clouds: the LM loop amplifies rounding (DESIGN section 4)
