@@ -40,6 +40,33 @@ def test_integration_notes_cover_every_entry_point():
     assert declared and not [n for n in sorted(declared) if n not in notes]
 
 
+def test_integration_snippets_pass_the_declared_number_of_arguments():
+    """Every `_lib.gs_*(...)` call in INTEGRATION.md's binding snippets has the arity of the bound signature."""
+    from gradslam_amd import _native
+
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    code = "\n".join(re.findall(r"```python\n(.*?)```", text, re.S))
+    calls = 0
+    for m in re.finditer(r"_lib\.(gs_[a-z0-9_]+)\(", code):
+        name, j, depth, nargs, cur = m.group(1), m.end(), 1, 0, ""
+        while depth > 0 and j < len(code):
+            ch = code[j]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if depth == 0:
+                break
+            if ch == "," and depth == 1:
+                nargs, cur = nargs + 1, ""
+            else:
+                cur += ch
+            j += 1
+        nargs += bool(cur.strip())
+        assert name in _native.SIGNATURES, name
+        assert nargs == len(_native.SIGNATURES[name][1]), (name, nargs, len(_native.SIGNATURES[name][1]))
+        calls += 1
+    assert calls >= 15
+
+
 def test_abi_is_plain_c():
     text = open(os.path.join(REPO, "include", "gradslam_hip.h")).read()
     code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
