@@ -355,3 +355,28 @@ def test_rgbdimages_plotly_export():
     assert len(fig.frames) == 3 and len(fig.layout.sliders[0].steps) == 3
     with pytest.raises(TypeError):
         r.plotly(0.0)
+
+
+def test_recorded_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (what `python bench.py` printed on the MI355X) carries every key of
+    the driver's contract, BASELINE.json's metric, and a consistent roofline / cpu_baseline."""
+    import glob
+    import json
+
+    lines = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench.json")))
+    assert lines
+    d = json.load(open(lines[-1]))
+    base = json.load(open(os.path.join(REPO, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"].replace("x", "×") in base["metric"].replace("x", "×") or "frames/sec" in d["metric"]
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
