@@ -46,9 +46,9 @@ SIGNATURES = {
     "gs_downsample_frame": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_build_icp_target_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "gs_build_icp_target": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                  c_p, c_sz, c_p]),
+                                  c_p, c_p, c_sz, c_p]),
     "gs_bucket_by_pixel_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
-    "gs_bucket_by_pixel": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_bucket_by_pixel": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_project_active_ws_bytes": (c_sz, [c_i, c_i]),
     "gs_project_active": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "gs_gather_table_rows_ws_bytes": (c_sz, [c_i]),
@@ -86,6 +86,7 @@ SIGNATURES = {
     "gs_slam_localize_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "gs_slam_localize": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f,
                                c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "gs_set_grid_search": (None, [c_i]),
     "gs_profile_enable": (None, [c_i]),
     "gs_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),
     "gs_fusion_similar": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
@@ -126,7 +127,7 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.gs_abi_version() != 1:
+        if handle.gs_abi_version() != 2:
             raise RuntimeError("gradslam_amd: ABI version mismatch")
         _lib = handle
     return _lib
@@ -150,8 +151,17 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def current_device_index() -> int:
+    """Index of the HIP device whose current stream `stream()` hands to the kernels."""
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
 def require_hip(*tensors, op: str = "op"):
-    """No CPU fallback: the hot path only runs on HIP tensors."""
+    """No CPU fallback: the hot path only runs on HIP tensors -- and only on the CURRENT device.  The C side
+    takes raw pointers and a stream and never calls hipSetDevice: launching on the current device's stream with
+    another device's pointers would fault, so a tensor elsewhere is an error here (one process per GPU, device
+    selected with torch.cuda.set_device, is the deployment model; parallel.init_from_env does that)."""
+    cur = None
     for t in tensors:
         if t is None:
             continue
@@ -159,6 +169,14 @@ def require_hip(*tensors, op: str = "op"):
             raise RuntimeError(
                 "gradslam_amd.{}: tensor is on {}; the ICP / PointFusion hot path only runs on a HIP "
                 "device (no CPU fallback is provided).".format(op, t.device)
+            )
+        if cur is None:
+            cur = current_device_index()
+        if t.device.index != cur:
+            raise RuntimeError(
+                "gradslam_amd.{}: tensor is on {} but the current HIP device is cuda:{}; kernels are launched on "
+                "the current device's stream -- call torch.cuda.set_device({}) (or wrap the call in "
+                "`with torch.cuda.device(...)`) first.".format(op, t.device, cur, t.device.index)
             )
 
 

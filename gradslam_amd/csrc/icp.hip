@@ -23,6 +23,8 @@
 //    exponential) runs in the prologue of the NEXT association launch, recomputed by every block, published by
 //    block 0; only a loop's last step is a launch of its own.  Buffers are addressed through device-side role
 //    indices, so accept/reject needs no host round trip and no copies.
+#include <stddef.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "gs_common.hpp"
@@ -34,11 +36,19 @@ constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving t
 constexpr int KNN_BT = KNN_NW * 64;
 constexpr int KNN_COARSE = 512; // target points sampled by the seed pass when no seed is given
 constexpr int CHUNK = 16;       // target points per AABB chunk
+constexpr int WROWS = 5;        // grid search: rows of the largest window (radius 2)
+constexpr int WBANDS = WROWS + 1;  // row bands a tile stages at most (its lanes sit in two adjacent rows)
+constexpr int SUPER = 64;       // chunks per super-box (= 1024 target points = one block of icp_prepare_k)
 constexpr int KNN_LIST = 4096;  // chunk boxes handled per round (capacity of the LDS survivor list)
 constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
 constexpr int LIN_MAXB = 1024;  // max partial blocks of the stand-alone J kernel (best of 512/1024/2048 measured at 2^24 points)
 constexpr unsigned long long KEY_NONE = ~0ull;
+// Grid search: the exact search that establishes a certificate looks at every box within CERT_REACH x the tile's
+// loosest neighbour distance (squared: x CERT_REACH^2), not only at those that could hold a nearer neighbour -- the
+// boxes beyond bound the certificate radius from below by that much, the ones inside by their own per-point bounds.
+constexpr float CERT_REACH2 = 1.0f;
+constexpr int GRID_MIN_PER_PIXEL = 4;  // grid search from this many targets per ds-grid pixel (average) on
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int j) {
     return ((unsigned long long)fbits(d) << 32) | (unsigned int)j;
@@ -168,13 +178,28 @@ __global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt,
 // re-read before every fine test, so a hit found by one wave prunes the others' remaining chunks.  A
 // stale read only prunes less, never wrongly.  All bounds use the distance's own operation order, so
 // bound <= distance holds exactly in fp32 (monotone rounding): the result is the brute-force scan's.
+constexpr int POOL = 4096;  // grid search: target points staged in LDS per tile (all window rows together): 64 KiB; two such
+                             // blocks share a CU (tools/micro/coresidency.hip: up to 80 KiB each)
+
 struct KnnShared {
     unsigned long long key[64];
-    int list[KNN_LIST];
     int cnt;
     float tbox[6];             // the source tile's AABB (lo.xyz, hi.xyz)
-    float rows[NACC][65];      // linearise epilogue: per-point products, padded against bank conflicts
-    float part[NACC][16];
+    // grid search (knn1_loop_k<true>): certificate bookkeeping
+    unsigned int m_tile;       // min tile-level bound over the chunks the coarse pass pruned (float bits)
+    unsigned int mm[64];       // per lane: min bound / distance over everything outside its window (float bits)
+    int win[WROWS][64];        // per lane: the packed window rows (LaneWin), from the staging waves
+    int wflag[64];             // per lane: rel | full << 2 | window radius << 3
+    int band[2 * WBANDS + 1];  // staged bands: first slot x WBANDS, pool offset x WBANDS, pool fill
+    float seed[2][64][4];      // the seed for either outcome of the step: target point, reference index bits
+    union alignas(16) {
+        struct {
+            int list[KNN_LIST];
+            float rows[NACC][65];  // linearise epilogue: per-point products, padded against bank conflicts
+            float part[NACC][16];
+        } a;
+        float stage[POOL * 4];  // window rows: (x, y, z, reference index bits) per target point
+    } u;
 };
 
 #ifdef GS_DIAG_STAMPS
@@ -183,16 +208,20 @@ __device__ unsigned long long *g_diag = nullptr;
 #define GS_STAMP(slot)                                                                                   \
     do {                                                                                                 \
         if (g_diag && (threadIdx.x & 63) == 0)                                                           \
-            g_diag[((size_t)blockIdx.x * KNN_NW + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64();    \
+            g_diag[((size_t)blockIdx.x * KNN_NW + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64();   \
     } while (0)
 #define GS_COUNT(slot, v)                                                                                \
     do {                                                                                                 \
         if (g_diag && (threadIdx.x & 63) == 0)                                                           \
-            g_diag[((size_t)blockIdx.x * KNN_NW + (threadIdx.x >> 6)) * 8 + (slot)] = (v);              \
+            g_diag[((size_t)blockIdx.x * KNN_NW + (threadIdx.x >> 6)) * 16 + (slot)] = (v);             \
     } while (0)
+#define GS_TICK(var) const unsigned int var = (unsigned int)wall_clock64()
+#define GS_ACCUM(acc, t0) acc += (unsigned int)wall_clock64() - (t0)
 #else
 #define GS_STAMP(slot)
 #define GS_COUNT(slot, v)
+#define GS_TICK(var)
+#define GS_ACCUM(acc, t0)
 #endif
 
 // wave-uniform broadcast of lane l's value (v_readlane_b32: no memory round trip)
@@ -267,6 +296,292 @@ __device__ __forceinline__ void knn_window_seed(KnnShared &sh, const f3 s, const
     __syncthreads();
 }
 
+// The source tile's box over the lanes selected by `act`: one wave per component, published through LDS
+// (the caller synchronises before reading sh.tbox).
+__device__ __forceinline__ void tile_box(KnnShared &sh, const f3 s, const bool act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= 1 && wave <= 6) {
+        const int a = wave - 1;
+        const float v = (a % 3 == 0) ? s.x : ((a % 3 == 1) ? s.y : s.z);
+        const float r = (a < 3) ? wave_min_f(act ? v : INFINITY) : wave_max_f(act ? v : -INFINITY);
+        if (lane == 0) sh.tbox[a] = r;
+    }
+}
+
+// Per-lane examined slot ranges of the grid search (three window rows, chunk aligned: a chunk whose first slot
+// lies in a range lies in it entirely).
+struct LaneWin {
+    // per window row: first chunk << 9 | number of chunks (<= POOL / CHUNK < 512); 0 = empty
+    __device__ __forceinline__ static int pack(int lo, int n) { return n > 0 ? ((lo / CHUNK) << 9) | ((n + CHUNK - 1) / CHUNK) : 0; }
+    __device__ __forceinline__ static int lo(int r) { return (r >> 9) * CHUNK; }
+    __device__ __forceinline__ static int len(int r, int nt) { return min((r & 511) * CHUNK, nt - lo(r)); }  // slots
+    // does the window of point `who` (rows in sh.win) contain the chunk that starts at `slot`?
+    __device__ __forceinline__ static bool covers(const KnnShared &sh, int who, int slot) {
+        const int c = slot / CHUNK;
+        // (the empty asm ties the LDS reads to this call: hoisted out of the search loops the rows would cost the
+        // registers that decide whether two blocks share a CU; a few LDS reads per box test are cheap on this rare path)
+        asm volatile("" : "+v"(who));
+        bool in = false;
+#pragma unroll
+        for (int r = 0; r < WROWS; ++r) {
+            const int w = sh.win[r][who];
+            in |= (unsigned)(c - (w >> 9)) < (unsigned)(w & 511);
+        }
+        return in;
+    }
+};
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ int sel4(int k, int a0, int a1, int a2, int a3) { return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3)); }
+
+// Exact search over the chunk boxes for the lanes selected by `act`, seeded by sh.key (tile box in sh.tbox, both
+// visible): coarse pass with the tile's box and loosest bound, fine pass with per-lane bounds (see knn_tile).
+// GRID: chunks inside a lane's own window `win` were examined already and are skipped for that lane; the smallest
+// bound / distance the lane sees OUTSIDE its window is accumulated into sh.mm[lane] and -- for the chunks the
+// coarse pass prunes for the whole tile -- sh.m_tile: together the lane's certificate radius (knn_grid_tile).
+// Ends with a barrier.
+template <bool GRID>
+__device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, const bool ok, const bool act,
+                                                 const float *__restrict__ scan, const int32_t *__restrict__ scan_orig,
+                                                 const float *__restrict__ boxes, const int nt, const float reach2 = 1.0f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int n_scanned = 0;
+    // the tile's box (from LDS) and its loosest bound (same 64 points in every wave -> same value)
+    float bd0;
+    int bi0;
+    key_unpack(sh.key[lane], bd0, bi0);
+    const float tlx = sh.tbox[0], tly = sh.tbox[1], tlz = sh.tbox[2];
+    const float thx = sh.tbox[3], thy = sh.tbox[4], thz = sh.tbox[5];
+    const float bdmax = wave_max_f(act ? bd0 : 0.0f) * (GRID ? reach2 : 1.0f);
+    float mm = INFINITY, mt = INFINITY;
+
+    const int nchunks = (nt + CHUNK - 1) / CHUNK;
+#ifdef GS_DIAG_STAMPS
+    unsigned int t_coarse = 0, t_fine = 0, t_bar = 0, n_tested = 0;
+#endif
+    for (int r0 = 0; r0 < nchunks; r0 += KNN_LIST) {
+        if (threadIdx.x == 0) sh.cnt = 0;
+        __syncthreads();
+        GS_TICK(tc0);
+        const int r1 = min(nchunks, r0 + KNN_LIST);
+        // coarse: lanes = chunk boxes; box-to-box gap with the distance's accumulation order
+        for (int c0 = r0 + wave * 64; c0 < r1; c0 += KNN_NW * 64) {
+            const int c = c0 + lane;
+            bool pass = false;
+            if (c < r1) {
+                const float *b = boxes + 6 * (int64_t)c;
+                const float ex = fmaxf(fmaxf(b[0] - thx, tlx - b[3]), 0.0f);
+                const float ey = fmaxf(fmaxf(b[1] - thy, tly - b[4]), 0.0f);
+                const float ez = fmaxf(fmaxf(b[2] - thz, tlz - b[5]), 0.0f);
+                const float lbt = (ex * ex + ey * ey) + ez * ez;
+                pass = lbt <= bdmax;
+                if (GRID && !pass) mt = fminf(mt, lbt);
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh.cnt, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (pass) sh.u.a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+            }
+        }
+        GS_ACCUM(t_coarse, tc0);
+        GS_TICK(tb0);
+        __syncthreads();
+        GS_ACCUM(t_bar, tb0);
+        GS_TICK(tf0);
+        // fine: survivors dealt round-robin to the waves, handled four at a time: ONE round of loads
+        // brings the boxes and the 4 x CHUNK candidate points of a group into registers (lane l holds
+        // point l%CHUNK of the group's survivor l/CHUNK), then tests and scans run without memory ops
+        const int nlist = sh.cnt;
+        const int ni = (nlist > wave) ? (nlist - wave + KNN_NW - 1) / KNN_NW : 0;
+        constexpr int SEG = 64 / CHUNK;
+        for (int g = 0; g < ni; g += SEG) {
+            const int seg = lane / CHUNK, idx = g + seg;
+            const bool have = idx < ni;
+            const int c = have ? sh.u.a.list[wave + KNN_NW * idx] : 0;
+            const int j = c * CHUNK + (lane % CHUNK);
+            const bool pv = have && j < nt;
+            const f3 q = pv ? ld3(scan, j) : f3{0.0f, 0.0f, 0.0f};
+            const int pj = pv ? (scan_orig ? scan_orig[j] : j) : 0x7fffffff;
+            float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+            if (have) {
+                const float *b = boxes + 6 * (int64_t)c;
+                b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3]; b4 = b[4]; b5 = b[5];
+            }
+            const int ng = min(SEG, ni - g);
+            for (int sg = 0; sg < ng; ++sg) {
+                const int l0 = sg * CHUNK;
+                float bd;
+                int bi;
+                key_unpack(sh.key[lane], bd, bi);
+                const float ex = fmaxf(fmaxf(rlane(b0, l0) - s.x, s.x - rlane(b3, l0)), 0.0f);
+                const float ey = fmaxf(fmaxf(rlane(b1, l0) - s.y, s.y - rlane(b4, l0)), 0.0f);
+                const float ez = fmaxf(fmaxf(rlane(b2, l0) - s.z, s.z - rlane(b5, l0)), 0.0f);
+                const float lb = (ex * ex + ey * ey) + ez * ez;
+                const int cc = __builtin_amdgcn_readlane(c, l0);
+                bool hit;
+                if (GRID) {
+                    const bool live = act & !LaneWin::covers(sh, lane, cc * CHUNK);  // not examined by this lane yet
+                    hit = live & (lb <= bd);
+                    mm = (live & !hit) ? fminf(mm, lb) : mm;
+                } else {
+                    hit = act & (lb <= bd);
+                }
+                // skip the chunk iff EVERY lane's bound is strictly above its best
+                if (!__any(hit)) continue;
+                const int m = min(CHUNK, nt - cc * CHUNK);
+                const float bdp = bd;
+                const int bip = bi;
+                float dmin = INFINITY;
+                for (int k = 0; k < m; ++k) {
+                    const float d = dist2(s, rlane(q.x, l0 + k), rlane(q.y, l0 + k), rlane(q.z, l0 + k));
+                    const int jj = __builtin_amdgcn_readlane(pj, l0 + k);
+                    const bool better = (d < bd) | ((d == bd) & (jj < bi));
+                    bd = better ? d : bd;
+                    bi = better ? jj : bi;
+                    if (GRID) dmin = fminf(dmin, d);
+                }
+                if (GRID) mm = hit ? fminf(mm, dmin) : mm;  // these candidates lie outside the lane's window
+                if (ok && (bd < bdp || bi < bip)) atomicMin(&sh.key[lane], pack_key(bd, bi));
+                ++n_scanned;
+            }
+#ifdef GS_DIAG_STAMPS
+            n_tested += ng;
+#endif
+        }
+        GS_ACCUM(t_fine, tf0);
+        if (GRID && r1 == nchunks) {  // last round: publish the certificate radii before the closing barrier
+            mt = wave_min_f(mt);
+            if (lane == 0) atomicMin(&sh.m_tile, fbits(mt));
+            if (act) atomicMin(&sh.mm[lane], fbits(mm));
+        }
+        GS_TICK(tb1);
+        __syncthreads();
+        GS_ACCUM(t_bar, tb1);
+    }
+    GS_COUNT(8, (unsigned long long)t_coarse);
+    GS_COUNT(9, (unsigned long long)t_fine);
+    GS_COUNT(10, (unsigned long long)t_bar);
+    GS_COUNT(11, (unsigned long long)n_tested);
+    GS_COUNT(4, (unsigned long long)n_scanned);
+    // diagnostic build: survivors of the last round | HW_ID << 16 | XCC_ID << 48 (which CU the block ran on)
+    GS_COUNT(5, (unsigned long long)sh.cnt | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
+                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 48));
+    (void)n_scanned;
+}
+
+// Exact search for a FEW points of the tile (bits of `need_mask`) by the whole block, two phases:
+//   A  lanes = super-boxes (SUPER chunks each): every point is tested against all of them with its own bound; a
+//      survivor becomes a (point, super-box) pair in the LDS list, the others bound the point's certificate radius;
+//   B  the pairs are dealt round-robin to the waves: lanes = the super-box's chunks, tested against the point's
+//      bound (chunks inside its window are skipped), survivors scanned at once, four per round, lanes = candidates.
+// For one or two stragglers this costs a fraction of the tile-level search -- what a converging loop needs once nearly
+// every certificate holds.  Same contract as knn_prune_search<true>: sh.mm[point] receives the smallest bound /
+// distance met outside the point's window.  sh.cnt must be zero on entry (all waves past their last use of the
+// list's storage); ends with a barrier.
+__device__ __forceinline__ void knn_point_search(KnnShared &sh, const f3 s, const unsigned long long need_mask,
+                                                 const float *__restrict__ scan, const int32_t *__restrict__ scan_orig,
+                                                 const float *__restrict__ boxes, const float *__restrict__ sboxes, const int nt,
+                                                 const float tau /* look into every super-box nearer than this (squared) */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = (nt + CHUNK - 1) / CHUNK, nsb = (nchunks + SUPER - 1) / SUPER;
+    for (unsigned long long rest = need_mask; rest; rest &= rest - 1) {  // phase A
+        const int L = __builtin_ctzll(rest);
+        const float px = rlane(s.x, L), py = rlane(s.y, L), pz = rlane(s.z, L);
+        float bd;
+        int bi;
+        key_unpack(sh.key[L], bd, bi);  // wave-uniform
+        float mm = INFINITY;
+        for (int b0 = wave * 64; b0 < nsb; b0 += KNN_NW * 64) {
+            const int sb = b0 + lane;
+            bool hit = false;
+            if (sb < nsb) {
+                const float *b = sboxes + 6 * (int64_t)sb;
+                const float ex = fmaxf(fmaxf(b[0] - px, px - b[3]), 0.0f);
+                const float ey = fmaxf(fmaxf(b[1] - py, py - b[4]), 0.0f);
+                const float ez = fmaxf(fmaxf(b[2] - pz, pz - b[5]), 0.0f);
+                const float lb = (ex * ex + ey * ey) + ez * ez;
+                hit = lb <= fmaxf(bd, tau);
+                if (!hit) mm = fminf(mm, lb);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh.cnt, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (hit && at < KNN_LIST) sh.u.a.list[at] = (L << 24) | sb;
+            }
+        }
+        mm = wave_min_f(mm);
+        if (lane == 0) atomicMin(&sh.mm[L], fbits(mm));
+    }
+    __syncthreads();
+    const int npairs = min(sh.cnt, KNN_LIST);  // (6 points x 4096 super-boxes would be 64 M targets: never truncated)
+    for (int pi = wave; pi < npairs; pi += KNN_NW) {  // phase B
+        const int pr = sh.u.a.list[pi];
+        const int L = pr >> 24, sb = pr & 0xffffff;
+        const f3 p{rlane(s.x, L), rlane(s.y, L), rlane(s.z, L)};
+        float bd;
+        int bi;
+        key_unpack(sh.key[L], bd, bi);
+        float mm = INFINITY;
+        const int c = sb * SUPER + lane;
+        bool hit = false;
+        if (c < nchunks && !LaneWin::covers(sh, L, c * CHUNK)) {
+            const float *b = boxes + 6 * (int64_t)c;
+            const float ex = fmaxf(fmaxf(b[0] - p.x, p.x - b[3]), 0.0f);
+            const float ey = fmaxf(fmaxf(b[1] - p.y, p.y - b[4]), 0.0f);
+            const float ez = fmaxf(fmaxf(b[2] - p.z, p.z - b[5]), 0.0f);
+            const float lb = (ex * ex + ey * ey) + ez * ez;
+            hit = lb <= bd;
+            if (!hit) mm = fminf(mm, lb);
+        }
+        unsigned long long hits = __ballot(hit);
+        while (hits) {  // four surviving chunks per round: lane l takes candidate l % CHUNK of the (l / CHUNK)-th of them
+            constexpr int SEG = 64 / CHUNK;
+            int cc = -1;
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) {
+                const int b0 = hits ? __builtin_ctzll(hits) : -1;
+                if (hits) hits &= hits - 1;
+                if (lane / CHUNK == q) cc = b0;
+            }
+            unsigned long long k = KEY_NONE;
+            if (cc >= 0) {
+                const int j = (sb * SUPER + cc) * CHUNK + (lane % CHUNK);
+                if (j < nt) {
+                    const f3 q = ld3(scan, j);
+                    const float d = dist2(p, q.x, q.y, q.z);
+                    k = pack_key(d, scan_orig ? scan_orig[j] : j);
+                    mm = fminf(mm, d);  // outside the point's window by construction
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(k, off, kWave);
+                k = o < k ? o : k;
+            }
+            if (k < pack_key(bd, bi)) {  // wave-uniform
+                if (lane == 0) atomicMin(&sh.key[L], k);
+                key_unpack(k, bd, bi);
+            }
+        }
+        mm = wave_min_f(mm);
+        if (lane == 0) atomicMin(&sh.mm[L], fbits(mm));
+    }
+    __syncthreads();
+}
+
 // returns the packed key of lane's point (KEY_NONE when there is no target)
 // tgt      : target points in REFERENCE order (seeds are reference indices; so are the returned ones)
 // scan     : the same points in the order they are scanned (== tgt when scan_orig is NULL); boxes are
@@ -278,7 +593,6 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
                                                        const float *__restrict__ boxes, const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     GS_STAMP(0);
-    int n_scanned = 0;
     if (wave == 0 && seed_j != -2) {  // -2: keys already seeded in LDS by knn_window_seed
         unsigned long long k0 = KEY_NONE;
         if (ok && seed_j >= 0) {
@@ -287,12 +601,7 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
         }
         sh.key[lane] = k0;
     }
-    if (wave >= 1 && wave <= 6) {  // the tile's box: one wave per component, published through LDS
-        const int a = wave - 1;
-        const float v = (a % 3 == 0) ? s.x : ((a % 3 == 1) ? s.y : s.z);
-        const float r = (a < 3) ? wave_min_f(ok ? v : INFINITY) : wave_max_f(ok ? v : -INFINITY);
-        if (lane == 0) sh.tbox[a] = r;
-    }
+    tile_box(sh, s, ok);
     __syncthreads();
     if (seed_j == -1) {
         // seed pass 1: a strided sample of KNN_COARSE target points, 16 per wave and step (uniform broadcast)
@@ -329,93 +638,8 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
         }
     }
     GS_STAMP(1);
-    // the tile's box (from LDS) and its loosest bound (same 64 points in every wave -> same value)
-    float bd0;
-    int bi0;
-    key_unpack(sh.key[lane], bd0, bi0);
-    const float tlx = sh.tbox[0], tly = sh.tbox[1], tlz = sh.tbox[2];
-    const float thx = sh.tbox[3], thy = sh.tbox[4], thz = sh.tbox[5];
-    const float bdmax = wave_max_f(ok ? bd0 : 0.0f);
-
-    const int nchunks = (nt + CHUNK - 1) / CHUNK;
-    for (int r0 = 0; r0 < nchunks; r0 += KNN_LIST) {
-        if (threadIdx.x == 0) sh.cnt = 0;
-        __syncthreads();
-        const int r1 = min(nchunks, r0 + KNN_LIST);
-        // coarse: lanes = chunk boxes; box-to-box gap with the distance's accumulation order
-        for (int c0 = r0 + wave * 64; c0 < r1; c0 += KNN_NW * 64) {
-            const int c = c0 + lane;
-            bool pass = false;
-            if (c < r1) {
-                const float *b = boxes + 6 * (int64_t)c;
-                const float ex = fmaxf(fmaxf(b[0] - thx, tlx - b[3]), 0.0f);
-                const float ey = fmaxf(fmaxf(b[1] - thy, tly - b[4]), 0.0f);
-                const float ez = fmaxf(fmaxf(b[2] - thz, tlz - b[5]), 0.0f);
-                pass = ((ex * ex + ey * ey) + ez * ez) <= bdmax;
-            }
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&sh.cnt, __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (pass) sh.list[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
-            }
-        }
-        __syncthreads();
-        // fine: survivors dealt round-robin to the waves, handled four at a time: ONE round of loads
-        // brings the boxes and the 4 x CHUNK candidate points of a group into registers (lane l holds
-        // point l%CHUNK of the group's survivor l/CHUNK), then tests and scans run without memory ops
-        const int nlist = sh.cnt;
-        const int ni = (nlist > wave) ? (nlist - wave + KNN_NW - 1) / KNN_NW : 0;
-        constexpr int SEG = 64 / CHUNK;
-        for (int g = 0; g < ni; g += SEG) {
-            const int seg = lane / CHUNK, idx = g + seg;
-            const bool have = idx < ni;
-            const int c = have ? sh.list[wave + KNN_NW * idx] : 0;
-            const int j = c * CHUNK + (lane % CHUNK);
-            const bool pv = have && j < nt;
-            const f3 q = pv ? ld3(scan, j) : f3{0.0f, 0.0f, 0.0f};
-            const int pj = pv ? (scan_orig ? scan_orig[j] : j) : 0x7fffffff;
-            float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-            if (have) {
-                const float *b = boxes + 6 * (int64_t)c;
-                b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3]; b4 = b[4]; b5 = b[5];
-            }
-            const int ng = min(SEG, ni - g);
-            for (int sg = 0; sg < ng; ++sg) {
-                const int l0 = sg * CHUNK;
-                float bd;
-                int bi;
-                key_unpack(sh.key[lane], bd, bi);
-                const float ex = fmaxf(fmaxf(rlane(b0, l0) - s.x, s.x - rlane(b3, l0)), 0.0f);
-                const float ey = fmaxf(fmaxf(rlane(b1, l0) - s.y, s.y - rlane(b4, l0)), 0.0f);
-                const float ez = fmaxf(fmaxf(rlane(b2, l0) - s.z, s.z - rlane(b5, l0)), 0.0f);
-                const float lb = (ex * ex + ey * ey) + ez * ez;
-                // skip the chunk iff EVERY lane's bound is strictly above its best
-                if (!__any(ok & (lb <= bd))) continue;
-                const int cc = __builtin_amdgcn_readlane(c, l0);
-                const int m = min(CHUNK, nt - cc * CHUNK);
-                const float bdp = bd;
-                const int bip = bi;
-                for (int k = 0; k < m; ++k) {
-                    const float d = dist2(s, rlane(q.x, l0 + k), rlane(q.y, l0 + k), rlane(q.z, l0 + k));
-                    const int jj = __builtin_amdgcn_readlane(pj, l0 + k);
-                    const bool better = (d < bd) | ((d == bd) & (jj < bi));
-                    bd = better ? d : bd;
-                    bi = better ? jj : bi;
-                }
-                if (ok && (bd < bdp || bi < bip)) atomicMin(&sh.key[lane], pack_key(bd, bi));
-                ++n_scanned;
-            }
-        }
-        __syncthreads();
-    }
+    knn_prune_search<false>(sh, s, ok, ok, scan, scan_orig, boxes, nt);
     GS_STAMP(2);
-    GS_COUNT(4, (unsigned long long)n_scanned);
-    // diagnostic build: survivors of the last round | HW_ID << 16 | XCC_ID << 48 (which CU the block ran on)
-    GS_COUNT(5, (unsigned long long)sh.cnt | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
-                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 48));
-    (void)n_scanned;
     GS_STAMP(3);
     return ok ? sh.key[lane] : KEY_NONE;
 }
@@ -516,20 +740,30 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
 // Fixed-order reduction of the per-block partials by a 1024-thread block into acc_sm[NACC]:
 // thread (g, k) = (t / 32, t % 32) sums rows g, g+32, g+64, ... of accumulator k (coalesced over k),
 // then 29 threads add the 32 group sums in order.  Two short LDS stages, no shuffle chains.
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm) {
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `after_issue` runs once, right after the first round of loads has been issued and before it is consumed: the
+// place for loads that should be in flight at the same time without delaying these (the grid search's staging).
+template <class Hook = NoHook>
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm,
+                                                Hook after_issue = Hook()) {
     __shared__ float stage[32][33];
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // blockDim.x == 1024 -> g in [0, 32)
     float v = 0.0f;
-    if (k < NACC) {
+    {
         // The rows were written by the previous launch on other CUs: every read is a trip to memory-side
         // cache (~1.5 us), so what matters is how many of them are in flight -- ten per thread and round.
-        for (int b0 = g; b0 < nblocks; b0 += 320) {
+        bool hooked = false;
+        for (int b0 = g; b0 < nblocks || !hooked; b0 += 320) {
             float a[10];
 #pragma unroll
             for (int u = 0; u < 10; ++u) {
                 const int b = b0 + 32 * u;
-                a[u] = b < nblocks ? partials[b * NACC + k] : 0.0f;
+                a[u] = (k < NACC && b < nblocks) ? partials[b * NACC + k] : 0.0f;
             }
+            if (!hooked) after_issue();
+            hooked = true;
 #pragma unroll
             for (int u = 0; u < 10; ++u) v += a[u];
         }
@@ -804,7 +1038,7 @@ __device__ void solve6_wave(const float *H, const float *g, float damp, float *x
     if (!ok && lane == 0) solve6_lu(H, g, damp, x, lu_buf);     // `ok` is wave-uniform: every lane saw the same pivots
 }
 
-// The O(1) step by a block (>= 64 threads, all of them call this; S and acc in LDS).  Wave 0 does the work, spread
+// The O(1) step by ONE wave (S and acc in LDS).  The work is spread
 // over its lanes where the data is wide -- expanding the 29 sums to H | g | e | n, adopting them, T = dT . T, the
 // tape / trace records -- so that the serial part is a handful of scalars:
 //   STEP_ADOPT : the look-ahead cloud becomes the current one unconditionally (initial cloud; gradICP's
@@ -821,13 +1055,22 @@ __device__ __forceinline__ float expand_elem(const float *acc, int t) {  // elem
     if (t < 42) return acc[21 + (t - 36)];
     return t == 42 ? acc[27] : acc[28];
 }
-__device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mode, GradParams gp, float *trace, float *out_T,
+// LDS hand-offs inside ONE wave: its LDS operations execute in issue order, so all that is needed is that the
+// compiler keeps them in program order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Called by the block's FIRST WAVE only (all 64 lanes of it): no block barrier inside, so the other waves are free to
+// do something else meanwhile (the grid search's staging); the caller synchronises the block afterwards.
+__device__ __forceinline__ void step_wave0(IcpState *S, const float *acc, int mode, GradParams gp, float *trace, float *out_T,
                                            int look_slot, float *rec, double *lu_buf, bool solve) {
     __shared__ float lin[44];
     __shared__ float sx[6];
     const int t = threadIdx.x;
     if (t < 44) lin[t] = expand_elem(acc, t);
-    __syncthreads();
+    wave_sync();
     const float err = S->cur[42], new_err = lin[42];
     const bool lm_accept = new_err < err;
     const bool adopt = mode == STEP_ADOPT || (mode == STEP_LM && lm_accept);
@@ -857,7 +1100,7 @@ __device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mo
             for (int i = 0; i < 6; ++i) sx[i] = sig * S->xi[i];
             se3_exp_dev(sx, S->dT);
         }
-        __syncthreads();
+        wave_sync();
     }
     // T = dT . T  (accepted LM step, every gradLM step): one lane per element, torch.mm's fma chain over k
     const bool mul_T = mode == STEP_GRAD_B || (mode == STEP_LM && lm_accept);
@@ -870,7 +1113,7 @@ __device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mo
         v = __fmaf_rn(S->dT[4 * i + 3], S->T[12 + j], v);
         new_T = v;
     }
-    __syncthreads();  // the old state has been read
+    wave_sync();  // the old state has been read
     if (adopt && t < 44) S->cur[t] = lin[t];
     if (mul_T && t < 16) S->T[t] = new_T;
     if (t == 0) {
@@ -883,14 +1126,14 @@ __device__ __forceinline__ void step_block(IcpState *S, const float *acc, int mo
         if (mode == STEP_LM) S->damp = lm_accept ? S->damp / 2.0f : S->damp * 2.0f;
         if (mode != STEP_ADOPT) S->it += 1;
     }
-    __syncthreads();
+    wave_sync();
     if (out_T && t < 16) out_T[t] = S->T[t];
-    if (solve && mode != STEP_GRAD_B) {  // block-uniform
-        if (t < 64) solve6_wave(S->cur, S->cur + 36, S->damp, S->xi, lu_buf);
-        __syncthreads();
+    if (solve && mode != STEP_GRAD_B) {  // wave-uniform
+        solve6_wave(S->cur, S->cur + 36, S->damp, S->xi, lu_buf);
+        wave_sync();
         if (t == 0) se3_exp_dev(S->xi, S->dT);
     }
-    __syncthreads();
+    wave_sync();
 }
 
 __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, const float *__restrict__ partials, int nblocks,
@@ -907,11 +1150,12 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 #endif
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
     reduce_partials(partials, nblocks, acc);  // ends with a barrier: st and acc are visible
-    if (rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(&st)[threadIdx.x];
+    // (from the global copy: wave 0 is about to change the LDS one)
+    if (rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[1] = wall_clock64();
 #endif
-    step_block(&st, acc, mode, gp, trace, out_T, look_slot, rec, lu_sm, solve != 0);
+    if (threadIdx.x < 64) step_wave0(&st, acc, mode, gp, trace, out_T, look_slot, rec, lu_sm, solve != 0);
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[2] = wall_clock64();
 #endif
@@ -934,52 +1178,214 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 // Then: in = (first ? user source : pts[p_cur]) transformed by dT, out = pts[out_slot], NN -> best[out_slot]
 // (out_slot < 0: the other one of the two ping-pong slots).  Seed: the current cloud's NN of the same source index
 // when there is one, else the sampled seed pass.
-__global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
-                                                      const float *__restrict__ partials_in, int nblocks_in, int step_mode,
-                                                      GradParams gp, float *__restrict__ trace, float *__restrict__ out_T,
-                                                      int look_slot, float *__restrict__ rec, int first, int out_slot,
-                                                      const float *__restrict__ user_src, LoopBufs B,
-                                                      const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
-                                                      const float *__restrict__ boxes, const int32_t *__restrict__ d_nt,
-                                                      const float *__restrict__ nrm, float thresh,
-                                                      float *__restrict__ partials /* gridDim.x x NACC */,
-                                                      gs_icp_hints hints) {
+//
+// GRID (all search hints given): the association is a GRID SEARCH WITH A DISTANCE CERTIFICATE.
+//   window      : the target is bucketed by ds-grid pixel (scan order, hints.pix_start).  Every lane examines ALL
+//                 targets of the 3 x 3 pixels around its window centre (three contiguous slot ranges, widened to whole
+//                 chunks), staged through LDS by coalesced loads issued before the folded step, so they cost no time.
+//                 The centre starts at the lane's own pixel and follows its neighbour (hints.tgt_pix) when that leaves
+//                 the window; the lanes of a tile move together, so their windows lie in at most four row bands,
+//                 each one contiguous slot range (row-major pixels), which share a pool of POOL staged points.
+//   certificate : what a lane has NOT examined is bounded from below -- the first association (and any later one a
+//                 lane needs) runs the exact chunk-box search for it and records m = the smallest bound / distance it
+//                 met outside the lane's window, together with the lane's position s_ref and window centre.  Later
+//                 associations of the same loop move the point a little (ICP steps): by the triangle inequality every
+//                 unexamined target is at least sqrt(m) - |s - s_ref| away, so if the best of the (same, fully
+//                 examined) window is strictly closer -- with a 1e-4 relative margin on every term, orders of magnitude
+//                 above fp32 rounding -- it IS the nearest neighbour, tie-break included, and no box is touched.  Lanes
+//                 that fail the test take the exact search again, restricted to them, and get a fresh certificate.
+// The result is the brute-force scan's in every case; only the cost differs (a later association of a converging
+// loop examines ~100 candidates per point instead of ~800 and tests no boxes).
+// What stays the same for every launch of one loop lives in the workspace (written once by icp_prepare_k), not in
+// the kernel arguments: at ~100 scalar registers a 1024-thread block no longer shares its CU with a second one (the
+// hardware admits floor(800 / (ceil(sgpr / 16) 16 + 16)) waves per SIMD: 8 up to 80 SGPRs, 7 from 82 on -- whatever
+// the compiler's occupancy estimate says), and the association kernel lives on that second block.
+struct LoopConst {
+    const float *user_src, *tgt, *nrm, *boxes, *sboxes;
+    const int32_t *d_ns, *d_nt;
+    float *trace, *out_T, *cert;
+    int32_t *cert_c;
+    gs_icp_hints hints;
+    GradParams gp;
+    float thresh;
+    int grid_min_per_pixel;
+    int grid_radius_max;   // largest window radius tried (2 or 1)
+    float cert_reach2;     // CERT_REACH2, tunable for measurements
+    int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
+};
+template <bool GRID>
+__global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
+                                                         const float *__restrict__ partials_in, int nblocks_in, int step_mode,
+                                                         int look_slot, float *__restrict__ rec, int first, int out_slot, LoopBufs B,
+                                                         float *__restrict__ partials /* gridDim.x x NACC */) {
     __shared__ KnnShared sh;
     __shared__ IcpState st_sm;
     __shared__ float acc_sm[NACC];
     __shared__ double lu_sm[42];
     constexpr int kWords = sizeof(IcpState) / 4;
     GS_STAMP(6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ns = C->ns, nt = C->nt;
+    const int tile0 = blockIdx.x * 64;
+    const int i = tile0 + lane;
+    const bool ok = i < ns;
+    const bool tile_live = tile0 < ns && nt > 0;
+    // The grid search pays where pixels hold several targets (a map that has seen many frames): chunk C->boxes are
+    // compact there and neighbour distances small against the pixel pitch, so certificates hold from the second
+    // association on.  On a sparse target (about one per pixel: C->boxes 16 pixels long, neighbours half a pixel away)
+    // they rarely do before the loop has converged, and the chunk-box search alone is faster.
+    const bool grid = GRID && (int64_t)nt >= (int64_t)C->grid_min_per_pixel * C->hints.grid_w * C->hints.grid_h;
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
+
+    // ---- the O(1) step is wave 0's; GRID: the other fifteen waves meanwhile work out the window of every lane and the
+    // row bands of the tile, stage the bands' targets into LDS and fetch the seed for either outcome of the step.
+    // Nothing of that depends on the step, so it costs the association no time.
     if (step_mode >= 0) {
-        const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
         reduce_partials(partials_in, nblocks_in, acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
-        if (pub && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(&st_sm)[threadIdx.x];
-        step_block(&st_sm, acc_sm, step_mode, gp, pub ? trace : nullptr, pub ? out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm,
-                   true);  // ends with a barrier
-        if (pub && threadIdx.x < kWords) {
-            const int v = reinterpret_cast<const int *>(&st_sm)[threadIdx.x];
-            reinterpret_cast<int *>(S_out)[threadIdx.x] = v;
-            if (rec) reinterpret_cast<int *>(rec)[REC_WORDS + REC_STATE + threadIdx.x] = v;
+        // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
+        if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
+    }
+    if (wave == 0) {
+        const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
+        if (step_mode >= 0)
+            step_wave0(&st_sm, acc_sm, step_mode, C->gp, pub ? C->trace : nullptr, pub ? C->out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm, true);
+    } else if (grid && tile_live) {
+        const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
+        const int h = ok ? min(max(C->hints.src_pix[i], 0), nc - 1) : 0;
+        int c = h;
+        if (ok && !first) {
+            const int cc = C->cert_c[i] & 0xffffff;  // (the window radius the certificate was made with rides in the top byte)
+            c = cc < nc ? cc : h;
         }
-    } else {
-        __syncthreads();
+        float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+        if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
+            int sj[2];
+            if (first) {
+                const int slot = min(max(C->hints.pix_start[h], 0), nt - 1);
+                sj[0] = sj[1] = min(max(C->hints.scan_orig[slot], 0), nt - 1);
+            } else {
+                const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
+                const unsigned long long ka = B.N(ba)[i], kb = B.N(bb)[i];
+                // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
+                sj[0] = (int)min((uint32_t)(ka & 0xffffffffu), (uint32_t)(nt - 1));
+                sj[1] = (int)min((uint32_t)(kb & 0xffffffffu), (uint32_t)(nt - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f3 q = ld3(C->tgt, sj[u]);
+                sd[u] = make_float4(q.x, q.y, q.z, __int_as_float(sj[u]));
+            }
+        }
+        // The lanes of a tile move together: their centres are their own pixels (consecutive in row-major order, also
+        // across a row end) plus nearly the same displacement.  Relative to the tile's smallest displacement a lane
+        // sits up to a pixel further along the row and / or one row further down (rel); what remains is contiguous
+        // in row-major order again, so every row band of the tile is ONE slot range.
+        // (wave reductions leave uniform values in vector registers: move them, and all that follows, to scalars)
+        const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i(ok ? c - h : 0x7fffffff));
+        const int e = ok ? c - h - dmin : 0;
+        int rel = ok ? (e >= Wd / 2) + (e >= Wd + Wd / 2) : 2;  // rel > 1: no window (a lane that does not move with its tile)
+        const bool in = ok && rel <= 1;
+        const int beta = c - rel * Wd;
+        const int bmin = __builtin_amdgcn_readfirstlane(wave_min_i(in ? beta : 0x7fffffff));
+        const int bmax = __builtin_amdgcn_readfirstlane(wave_max_i(in ? beta : (int)0x80000000));
+        const bool two_rows = __any(in && rel == 1);
+        auto slot_lo = [&](int cell) { return min(max(C->hints.pix_start[cell], 0), nt) & ~(CHUNK - 1); };
+        auto slot_hi = [&](int cell) { return min((min(max(C->hints.pix_start[cell + 1], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt); };
+        // Window radius: 2 (5 x 5 pixels) while the bands of the tile fit the pool -- a sparse target, where the
+        // wider window is what gives the certificate its margin -- else 1 (3 x 3).  Band kk covers the pixels
+        // [bmin + (kk - R) Wd - R, bmax + (kk - R) Wd + R], kk = 0 .. 2 R (+ 1 if the lanes sit in two rows).
+        int bbase[WBANDS], boff[WBANDS], bcnt[WBANDS], used = 0, R = 2;
+        auto lay_bands = [&](int rad) {
+            used = 0;
+            bool fits = true;
+#pragma unroll
+            for (int kk = 0; kk < WBANDS; ++kk) {
+                bbase[kk] = 0; bcnt[kk] = 0; boff[kk] = used;
+                const int a = bmin + (kk - rad) * Wd - rad, b = bmax + (kk - rad) * Wd + rad;
+                if (kk <= 2 * rad + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1) {
+                    const int lo = slot_lo(max(a, 0)), hi = slot_hi(min(b, nc - 1));
+                    if (hi > lo) {
+                        bbase[kk] = lo; bcnt[kk] = hi - lo;
+                        // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
+                        // window stays complete and with it the certificate): pool offset -1
+                        if (used + (hi - lo) <= POOL) used += hi - lo; else { boff[kk] = -1; fits = false; }
+                    }
+                }
+            }
+            return fits;
+        };
+        if (C->grid_radius_max < 2 || !lay_bands(2)) { R = 1; lay_bands(1); }
+        // staging loads first (they are the long ones), the per-lane rows behind them
+        constexpr int ST = KNN_BT - 64, NR = (POOL + ST - 1) / ST;
+        float4 sreg[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = (int)threadIdx.x - 64 + ST * r;
+            if (e < used) {
+                int bb = 0, bo = 0;  // the staged band that holds pool element e: the last one that starts at or before it
+#pragma unroll
+                for (int q = 0; q < WBANDS; ++q) {
+                    const bool here = boff[q] >= 0 && bcnt[q] > 0 && e >= boff[q];
+                    bb = here ? bbase[q] : bb; bo = here ? boff[q] : bo;
+                }
+                const int slot = bb + e - bo;
+                const f3 q3 = ld3(C->hints.scan_points, slot);
+                sreg[r] = make_float4(q3.x, q3.y, q3.z, __int_as_float(C->hints.scan_orig[slot]));
+            }
+        }
+        if (wave == 1) {
+            bool full = in;
+#pragma unroll
+            for (int r = 0; r < WROWS; ++r) {
+                int packed = 0;
+                const int g = c + (r - R) * Wd;
+                if (in && r <= 2 * R && g + R >= 0 && g - R <= nc - 1) {
+                    const int lo = slot_lo(max(g - R, 0)), hi = slot_hi(min(g + R, nc - 1));
+                    if (hi > lo) {
+                        int bb = bbase[0], bn = bcnt[0];
+#pragma unroll
+                        for (int q = 1; q < WBANDS; ++q) { bb = (rel + r) == q ? bbase[q] : bb; bn = (rel + r) == q ? bcnt[q] : bn; }
+                        // inside the staged band, or not examined (then the lane has no certificate: `full`)
+                        if (lo >= bb && hi <= bb + bn) packed = LaneWin::pack(lo, hi - lo); else full = false;
+                    }
+                }
+                sh.win[r][lane] = packed;
+            }
+            sh.wflag[lane] = min(rel, 2) | (full ? 4 : 0) | (R << 3);
+            sh.key[lane] = KEY_NONE;
+            sh.mm[lane] = fbits(INFINITY);
+            if (lane == 0) { sh.m_tile = fbits(INFINITY); sh.cnt = 0; sh.band[2 * WBANDS] = used; }
+            if (lane < WBANDS) {
+                int bb = bbase[0], bo = boff[0];
+#pragma unroll
+                for (int q = 1; q < WBANDS; ++q) { bb = lane == q ? bbase[q] : bb; bo = lane == q ? boff[q] : bo; }
+                sh.band[lane] = bb; sh.band[WBANDS + lane] = bo;
+            }
+            *reinterpret_cast<float4 *>(sh.seed[0][lane]) = sd[0];
+            *reinterpret_cast<float4 *>(sh.seed[1][lane]) = sd[1];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = (int)threadIdx.x - 64 + ST * r;
+            if (e < used) *reinterpret_cast<float4 *>(&sh.u.stage[4 * e]) = sreg[r];
+        }
+    }
+    __syncthreads();
+    if (step_mode >= 0 && blockIdx.x == 0 && threadIdx.x < kWords) {
+        const int v = reinterpret_cast<const int *>(&st_sm)[threadIdx.x];
+        reinterpret_cast<int *>(S_out)[threadIdx.x] = v;
+        if (rec) reinterpret_cast<int *>(rec)[REC_WORDS + REC_STATE + threadIdx.x] = v;
     }
     GS_STAMP(7);
     const IcpState *S = &st_sm;
-    const int ns = *d_ns, nt = *d_nt;
-    const int tile0 = blockIdx.x * 64;
     if (tile0 >= ns) {  // empty tile: its partial row must still be defined
         if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
         return;
     }
     const int p_cur = S->p_cur, b_cur = S->b_cur;
-    const float *in = first ? user_src : B.P(p_cur);
+    const float *in = first ? C->user_src : B.P(p_cur);
     float *out = B.P(out_slot >= 0 ? out_slot : 1 - p_cur);
     unsigned long long *best = B.N(out_slot >= 0 ? out_slot : 1 - b_cur);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = tile0 + lane;
-    const bool ok = i < ns;
     f3 s{0.0f, 0.0f, 0.0f};
     if (ok) {
         s = xform(S->dT, ld3(in, i));
@@ -990,42 +1396,150 @@ __global__ __launch_bounds__(KNN_BT) void knn1_loop_k(const IcpState *__restrict
         if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
         return;
     }
-    int sj = -1;
-    if (!first) {
-        sj = 0;
-        if (ok) {
-            const unsigned long long k = B.N(b_cur)[i];
-            sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
+    unsigned long long key;
+    bool need = false;
+    float m_new = 0.0f;
+    int rel = 2;  // grid search: the lane's centre row relative to the tile's first (0 / 1), | 4 = window fully staged
+    if (grid) {
+        GS_STAMP(0);
+        rel = sh.wflag[lane];
+        // the lane's certificate, and the seed: one real candidate per lane, fetched for either outcome of the step
+        float4 cf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int cert_R = 0;
+        if (ok && !first) {
+            cf = *reinterpret_cast<const float4 *>(C->cert + 4 * (int64_t)i);
+            cert_R = C->cert_c[i] >> 24;
         }
+        if (wave == 0) {
+            unsigned long long k0 = KEY_NONE;
+            if (ok) {
+                const int u = (first || b_cur == S_in->b_cur) ? 0 : 1;
+                const float4 q = *reinterpret_cast<const float4 *>(sh.seed[u][lane]);
+                k0 = pack_key(dist2(s, q.x, q.y, q.z), __float_as_int(q.w));
+            }
+            atomicMin(&sh.key[lane], k0);
+        }
+        {   // window: every wave takes every 16th slot of the lane's row ranges
+            float bd = INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < WROWS; ++r) {
+                const int wr = sh.win[r][lane];
+                const int kk = (rel & 3) + r, wn = LaneWin::len(wr, nt);
+                const int po = sh.band[WBANDS + min(kk, WBANDS - 1)];
+                const float *row = sh.u.stage + 4 * (max(po, 0) + LaneWin::lo(wr) - sh.band[min(kk, WBANDS - 1)]);
+                for (int p = wave; p < wn; p += KNN_NW) {
+                    float4 q;
+                    if (po >= 0) {
+                        q = *reinterpret_cast<const float4 *>(row + 4 * p);
+                    } else {  // band not staged: straight from memory
+                        const int slot = LaneWin::lo(wr) + p;
+                        const f3 g3 = ld3(C->hints.scan_points, slot);
+                        q = make_float4(g3.x, g3.y, g3.z, __int_as_float(C->hints.scan_orig[slot]));
+                    }
+                    const float d = dist2(s, q.x, q.y, q.z);
+                    const int jj = __float_as_int(q.w);
+                    const bool better = (d < bd) | ((d == bd) & (jj < bi));
+                    bd = better ? d : bd;
+                    bi = better ? jj : bi;
+                }
+            }
+            if (ok && bd < INFINITY) atomicMin(&sh.key[lane], pack_key(bd, bi));
+        }
+        __syncthreads();
+        GS_STAMP(1);
+        float bd;
+        int bi;
+        key_unpack(sh.key[lane], bd, bi);
+        // certificate: unexamined targets are >= sqrt(m) - |s - s_ref| away (margins: see the kernel comment)
+        const float moved = sqrtf(dist2(s, cf.x, cf.y, cf.z));
+        const float reach = sqrtf(cf.w) * 0.9999f - moved * 1.0001f;
+        // (the same window: same centre by construction, at least the radius the certificate was made with, all of it staged)
+        const bool proven = ((rel & 4) != 0) & ((rel >> 3) >= cert_R) & (cf.w > 0.0f) & (reach > 0.0f) & (bd * 1.0001f < reach * reach);
+        need = ok & !proven;
+#ifdef GS_DIAG_STAMPS
+        {   // why certificates fail (diagnostic build): lanes per reason, and the tile's mean radii in micrometres
+            const bool c_full = (rel & 4) != 0, c_rad = (rel >> 3) >= cert_R, c_m = cf.w > 0.0f, c_reach = reach > 0.0f;
+            const unsigned long long n1 = __popcll(__ballot(ok & !c_full)), n2 = __popcll(__ballot(ok & c_full & !c_rad)),
+                                     n3 = __popcll(__ballot(ok & c_full & c_rad & !c_m)), n4 = __popcll(__ballot(ok & c_full & c_rad & c_m & !c_reach)),
+                                     n5 = __popcll(__ballot(ok & c_full & c_rad & c_m & c_reach & !proven));
+            GS_COUNT(13, n1 | (n2 << 8) | (n3 << 16) | (n4 << 24) | (n5 << 32) | ((unsigned long long)(rel >> 3) << 40));
+            const float nn = fmaxf((float)__popcll(__ballot(ok & c_m)), 1.0f);
+            const unsigned long long um_m = (unsigned long long)(1e6f * wave_sum((ok & c_m) ? sqrtf(cf.w) : 0.0f) / nn),
+                                     um_mv = (unsigned long long)(1e6f * wave_sum((ok & c_m) ? moved : 0.0f) / nn),
+                                     um_bd = (unsigned long long)(1e6f * wave_sum((ok & c_m) ? sqrtf(bd) : 0.0f) / nn);
+            GS_COUNT(14, (um_m & 0xfffff) | ((um_mv & 0xfffff) << 20) | ((um_bd & 0xfffff) << 40));
+        }
+#endif
+        const unsigned long long need_mask = __ballot(need);  // the same 64 lanes in every wave: block-uniform
+        GS_COUNT(12, (unsigned long long)__popcll(need_mask));
+        if (__popcll(need_mask) > 6) {
+            tile_box(sh, s, need);
+            __syncthreads();
+            knn_prune_search<true>(sh, s, ok, need, C->hints.scan_points, C->hints.scan_orig, C->boxes, nt, C->cert_reach2);  // ends with a barrier
+            m_new = fminf(bitsf(sh.mm[lane]), bitsf(sh.m_tile));
+        } else if (need_mask) {
+            knn_point_search(sh, s, need_mask, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt,
+                             C->cert_reach2 * wave_max_f(ok ? bd : 0.0f));  // ends with a barrier
+            m_new = bitsf(sh.mm[lane]);
+        }
+        GS_STAMP(2);
+        key = ok ? sh.key[lane] : KEY_NONE;
+        GS_STAMP(3);
+    } else {
+        int sj = -1;
+        if (!first) {
+            sj = 0;
+            if (ok) {
+                const unsigned long long k = B.N(b_cur)[i];
+                sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
+            }
+        }
+        const bool window_seed = first && C->hints.scan_points && C->hints.src_pix && C->hints.pix_start && C->hints.grid_w > 0;
+        if (window_seed) sj = -2;  // seeded by knn_window_seed below (block-uniform decision)
+        const float *scan = C->hints.scan_points ? C->hints.scan_points : C->tgt;
+        const int32_t *scan_orig = C->hints.scan_points ? C->hints.scan_orig : nullptr;
+        if (window_seed) knn_window_seed(sh, s, ok, i, C->hints, nt);
+        key = knn_tile(sh, s, ok, sj, C->tgt, scan, scan_orig, C->boxes, nt);
     }
-    const bool window_seed = first && hints.scan_points && hints.src_pix && hints.pix_start && hints.grid_w > 0;
-    if (window_seed) sj = -2;  // seeded by knn_window_seed below (block-uniform decision)
-    const float *scan = hints.scan_points ? hints.scan_points : tgt;
-    const int32_t *scan_orig = hints.scan_points ? hints.scan_orig : nullptr;
-    if (window_seed) knn_window_seed(sh, s, ok, i, hints, nt);
-    const unsigned long long key = knn_tile(sh, s, ok, sj, tgt, scan, scan_orig, boxes, nt);
     // linearise this tile straight away (J fused into K's epilogue): 29 sums over the tile's 64 points,
     // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
     if (wave == 0) {
         if (ok) best[i] = key;
+        if (grid && need && key != KEY_NONE) {
+            // fresh certificate.  It holds for THIS window; a neighbour outside the window moves the centre there and
+            // leaves the lane without a certificate until the next exact search has bounded the new window's outside.
+            const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h, R = rel >> 3;
+            int centre = min(max(C->hints.src_pix[i], 0), nc - 1);
+            if (!first) {
+                const int cc = C->cert_c[i] & 0xffffff;
+                centre = cc < nc ? cc : centre;
+            }
+            const int cstar = C->hints.tgt_pix ? min(max(C->hints.tgt_pix[(uint32_t)(key & 0xffffffffu)], 0), nc - 1) : centre;
+            // the neighbour should sit in the inner part of the window (one pixel of margin to its rim)
+            const int keep = max(R - 1, 1);
+            const bool inside = abs(cstar / Wd - centre / Wd) <= keep && abs(cstar % Wd - centre % Wd) <= keep;
+            *reinterpret_cast<float4 *>(C->cert + 4 * (int64_t)i) = make_float4(s.x, s.y, s.z, (inside && (rel & 4)) ? m_new : 0.0f);
+            C->cert_c[i] = (inside ? centre : cstar) | (R << 24);
+        }
         float acc[NACC];
 #pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-        const Row r = make_row_from(s, ok, key, tgt, nrm, thresh);
+        const Row r = make_row_from(s, ok, key, C->tgt, C->nrm, C->thresh);
         if (r.valid) accumulate_row(r, acc);
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) sh.rows[k][lane] = acc[k];
+        for (int k = 0; k < NACC; ++k) sh.u.a.rows[k][lane] = acc[k];
     }
     __syncthreads();
     if (threadIdx.x < NACC * 16) {
         const int k = threadIdx.x >> 4, p4 = (threadIdx.x & 15) * 4;
-        sh.part[k][threadIdx.x & 15] = ((sh.rows[k][p4] + sh.rows[k][p4 + 1]) + sh.rows[k][p4 + 2]) + sh.rows[k][p4 + 3];
+        sh.u.a.part[k][threadIdx.x & 15] = ((sh.u.a.rows[k][p4] + sh.u.a.rows[k][p4 + 1]) + sh.u.a.rows[k][p4 + 2]) + sh.u.a.rows[k][p4 + 3];
     }
     __syncthreads();
     if (threadIdx.x < NACC) {
         float v = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v += sh.part[threadIdx.x][q];
+        for (int q = 0; q < 16; ++q) v += sh.u.a.part[threadIdx.x][q];
         partials[blockIdx.x * NACC + threadIdx.x] = v;
     }
 }
@@ -1044,10 +1558,20 @@ __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T /
     }
 }
 
-// one launch for the loop's two preparations: initial state (one lane) and the target's chunk boxes
-__global__ __launch_bounds__(64) void icp_prepare_k(IcpState *S, const float *__restrict__ init_T, float damp,
-                                                    const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
-                                                    float *__restrict__ boxes) {
+// one launch for the loop's preparations: initial state (one lane), the target's chunk boxes and, per SUPER = 64
+// chunks (one block), their common box -- the second level the point-serial search consults first
+__global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, const float *__restrict__ init_T, float damp,
+                                                              const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
+                                                              float *__restrict__ boxes, float *__restrict__ sboxes,
+                                                              LoopConst lc, LoopConst *__restrict__ lc_out) {
+    static_assert(SUPER * CHUNK == 1024, "one block per super-box");
+    __shared__ float wb[16][6];
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(LoopConst) / 4) {  // the loop's constants, for its association launches
+        int v = reinterpret_cast<const int *>(&lc)[threadIdx.x];
+        if (threadIdx.x == offsetof(LoopConst, ns) / 4) v = *lc.d_ns;
+        if (threadIdx.x == offsetof(LoopConst, nt) / 4) v = *lc.d_nt;
+        reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
+    }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int i = 0; i < 16; ++i) {
             const float v = init_T ? init_T[i] : ((i % 5 == 0) ? 1.0f : 0.0f);
@@ -1061,8 +1585,8 @@ __global__ __launch_bounds__(64) void icp_prepare_k(IcpState *S, const float *__
         S->it = 0;
     }
     const int nt = *d_nt;
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.x * 64 >= nt) return;
+    const int j = blockIdx.x * (SUPER * CHUNK) + threadIdx.x;
+    if (blockIdx.x * (SUPER * CHUNK) >= nt) return;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (j < nt) {
         const f3 p = ld3(tgt, j);
@@ -1079,6 +1603,23 @@ __global__ __launch_bounds__(64) void icp_prepare_k(IcpState *S, const float *__
     if ((threadIdx.x % CHUNK) == 0 && j < nt) {
         float *b = boxes + 6 * (int64_t)(j / CHUNK);
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+    }
+    // the block's box: finish the wave reduction, then the sixteen waves through LDS
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off >= CHUNK; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, kWave));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { wb[wave][0] = lo[0]; wb[wave][1] = lo[1]; wb[wave][2] = lo[2]; wb[wave][3] = hi[0]; wb[wave][4] = hi[1]; wb[wave][5] = hi[2]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = wb[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w) v = threadIdx.x < 3 ? fminf(v, wb[w][threadIdx.x]) : fmaxf(v, wb[w][threadIdx.x]);
+        sboxes[6 * (int64_t)blockIdx.x + threadIdx.x] = v;
     }
 }
 
@@ -1133,11 +1674,16 @@ static inline void prof_mark(int tag, int which, hipStream_t st) {
 
 bool profiling_enabled() { return g_prof.on; }
 
+static int g_grid_mode = 1;  // gs_set_grid_search
+
 struct IcpWs {
     IcpState *S[2];      // double-buffered across launches (see knn1_loop_k)
     LoopBufs B;
     float *partials[2];
-    float *boxes;
+    float *boxes, *sboxes;  // chunk boxes, and one box per SUPER chunks
+    float *cert;         // grid search: (max_ns, 4) certificate per source point (knn1_loop_k<true>)
+    int32_t *cert_c;     // grid search: (max_ns) window centre of every source point
+    LoopConst *lc;       // the loop's constants (knn1_loop_k reads them from here, not from its arguments)
 };
 static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out) {
     size_t off = 0;
@@ -1146,7 +1692,8 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
     const size_t oPart = take((size_t)cdiv(max_ns, 64) * NACC * 4), oPart1 = take((size_t)cdiv(max_ns, 64) * NACC * 4);
-    const size_t oBox = take(boxes_bytes(max_nt));
+    const size_t oBox = take(boxes_bytes(max_nt)), oSBox = take((size_t)cdiv(max_nt > 0 ? max_nt : 1, 1024) * 6 * 4);
+    const size_t oCert = take((size_t)max_ns * 16), oCertC = take((size_t)max_ns * 4), oLc = take(sizeof(LoopConst));
     if (ws && out) {
         char *p = (char *)ws;
         out->S[0] = (IcpState *)(p + oS); out->S[1] = (IcpState *)(p + oS1);
@@ -1156,6 +1703,10 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
         out->B.best_stride = (int64_t)(oB1 - oB0) / 8;
         out->partials[0] = (float *)(p + oPart); out->partials[1] = (float *)(p + oPart1);
         out->boxes = (float *)(p + oBox);
+        out->sboxes = (float *)(p + oSBox);
+        out->cert = (float *)(p + oCert);
+        out->cert_c = (int32_t *)(p + oCertC);
+        out->lc = (LoopConst *)(p + oLc);
     }
     return off;
 }
@@ -1189,8 +1740,9 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
                    const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp, float thresh,
                    GradParams gp, const gs_icp_hints *hints_in, float *out_T, uint64_t *best_last, float *trace, void *ws,
                    size_t ws_bytes, hipStream_t st, const char *name, void *tape = nullptr, size_t tape_bytes = 0,
-                   const float *compose_right = nullptr, float *compose_out = nullptr) {
-    gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, 0, 0};
+                   const float *compose_right = nullptr, float *compose_out = nullptr,
+                   int dense_hint = -1 /* caller's knowledge of the target's density: 1 dense, 0 sparse, -1 judge by max_nt */) {
+    gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
     GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && out_T, "%s: NULL argument", name);  // init_T NULL = identity
@@ -1224,8 +1776,14 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int lb = (int)kgrid.x;  // one partial row per 64-point tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
 
-    hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, 64)), dim3(64), 0, st, w.S[0], init_T, damp,
-                       hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes);
+    static const int grid_min_env = getenv("GS_GRID_MIN_PER_PIXEL") ? atoi(getenv("GS_GRID_MIN_PER_PIXEL")) : GRID_MIN_PER_PIXEL;
+    const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
+    static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 1;
+    static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
+    const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, hints, gp, thresh, grid_min, grid_rmax,
+                       cert_reach2, 0, 0};
+    hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
+                       hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
     // The loop as a sequence  A S A S ... A S  (A = association + linearise launch, S = O(1) step on A's sums).
     // Every S but the last runs in the prologue of the A that follows it; state and partial sums alternate
@@ -1238,6 +1796,14 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     // the kernel is throughput-bound and 4 us of redundant work in EVERY block costs more than one small launch:
     // then each step is a launch of its own again (measured at 78 k source points: 1225 blocks).
     const bool fold = (int)kgrid.x <= 2 * 256;
+    // all hints given: grid search with distance certificates (knn1_loop_k<true>); GS_NO_GRID_SEARCH=1 keeps the
+    // chunk-box search for every association (same results; for A/B measurements and tests)
+    static const bool grid_off = getenv("GS_NO_GRID_SEARCH") != nullptr;
+    // ... and only where the target can be dense enough for it (the kernel checks the actual count again): the grid
+    // variant carries more registers and 32 bytes of scratch, 1.4 us per launch on a sparse target
+    const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
+                             hints.grid_w > 0 && hints.grid_h > 0 &&
+                             (g_grid_mode == 2 || (dense_hint != 0 && (dense_hint > 0 || (int64_t)max_nt >= (int64_t)grid_min * hints.grid_w * hints.grid_h)));
     auto assoc = [&](int first) {
         if (!fold && pending >= 0) {  // stand-alone step, state updated in place
             hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S[cur], w.partials[cur], lb, pending, gp, trace, out_T,
@@ -1248,9 +1814,15 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         }
         const int nxt = pending >= 0 ? 1 - cur : cur;  // a folded step publishes the new state to the other buffer
         prof_mark(0, 0, st);
-        hipLaunchKernelGGL(knn1_loop_k, kgrid, dim3(KNN_BT), 0, st, w.S[cur], w.S[nxt], w.partials[cur], lb, pending, gp, trace,
-                           out_T, pending_slot, (tape && pending >= 0) ? tp.rec + (size_t)n_step * REC_WORDS : nullptr, first,
-                           tape ? n_assoc : -1, src, w.B, d_ns, tgt, w.boxes, d_nt, nrm, thresh, w.partials[nxt], hints);
+        float *rec_p = (tape && pending >= 0) ? tp.rec + (size_t)n_step * REC_WORDS : nullptr;
+        if (grid_search)
+            hipLaunchKernelGGL(knn1_loop_k<true>, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
+                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first, tape ? n_assoc : -1, w.B,
+                               w.partials[nxt]);
+        else
+            hipLaunchKernelGGL(knn1_loop_k<false>, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
+                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first, tape ? n_assoc : -1, w.B,
+                               w.partials[nxt]);
         prof_mark(0, 1, st);
         if (pending >= 0) ++n_step;
         cur = nxt;
@@ -1721,12 +2293,12 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
 int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                      const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
                      float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
-                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out) {
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint) {
     const GradParams gp = grad_lm ? GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max),
                                                Bp, B2, (float)(1.0 / (double)nu)}
                                   : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f};
     return icp_run(grad_lm != 0, src, d_ns, max_ns, tgt, nrm, d_nt, max_nt, nullptr, numiters, damp, thresh, gp, hints, out_T, nullptr,
-                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out);
+                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out, dense_hint);
 }
 
 }  // namespace gs
@@ -1740,6 +2312,8 @@ int gs_diag_set_buffer(void *p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &p, sizeof(p));
 }
 #endif
+
+void gs_set_grid_search(int on) { g_grid_mode = on; }
 
 void gs_profile_enable(int on) {
     g_prof.on = on != 0;

@@ -268,16 +268,19 @@ __global__ __launch_bounds__(1024) void pix_scan_k(const int *__restrict__ cnt, 
 __global__ void pix_scatter_k(const int64_t *__restrict__ rows, const int32_t *__restrict__ d_n,
                               const int32_t *__restrict__ starts, int Wd, int npix, int ds,
                               const int *__restrict__ start, int *__restrict__ fill, const float *__restrict__ map_points,
-                              int Nmax, int cap, float *__restrict__ scan_pts, int32_t *__restrict__ scan_orig) {
+                              int Nmax, int cap, float *__restrict__ scan_pts, int32_t *__restrict__ scan_orig,
+                              int32_t *__restrict__ tgt_pix /* or NULL */) {
     const int n = *d_n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const longlong4 r = *reinterpret_cast<const longlong4 *>(rows + 4 * i);
         const int b = (int)r.x;
         const int pix = (int)(r.z / ds) * Wd + (int)(r.w / ds);
+        const int k = (int)(i - starts[b]);
+        if (tgt_pix && k < cap) tgt_pix[(int64_t)b * cap + k] = pix;
         const int slot = start[(int64_t)b * (npix + 1) + pix] + atomicAdd(fill + (int64_t)b * npix + pix, 1);
         if (slot >= cap) continue;
         st3(scan_pts, (int64_t)b * cap + slot, ld3(map_points, (int64_t)b * Nmax + r.y));
-        scan_orig[(int64_t)b * cap + slot] = (int32_t)(i - starts[b]);
+        scan_orig[(int64_t)b * cap + slot] = (int32_t)k;
     }
 }
 // fused front of the ICP target build: reference-order gather of points + normals AND the per-pixel
@@ -325,7 +328,8 @@ __global__ void tgt_scatter_gather1_k(const int64_t *__restrict__ rows, const in
                                       const float *__restrict__ map_points, const float *__restrict__ map_normals, int cap,
                                       float *__restrict__ tgt, float *__restrict__ tnrm, int32_t *__restrict__ counts,
                                       int32_t *__restrict__ tgt_index, int Wd, int ds, const int *__restrict__ start,
-                                      int *__restrict__ fill, float *__restrict__ scan_pts, int32_t *__restrict__ scan_orig) {
+                                      int *__restrict__ fill, float *__restrict__ scan_pts, int32_t *__restrict__ scan_orig,
+                                      int32_t *__restrict__ tgt_pix /* or NULL */) {
     const int n = *d_n;
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -337,6 +341,7 @@ __global__ void tgt_scatter_gather1_k(const int64_t *__restrict__ rows, const in
             if (tgt_index) tgt_index[i] = (int32_t)r.y;
         }
         const int pix = (int)(r.z / ds) * Wd + (int)(r.w / ds);
+        if (tgt_pix && i < cap) tgt_pix[i] = pix;
         const int slot = start[pix] + atomicAdd(fill + pix, 1);
         if (slot >= cap) continue;
         st3(scan_pts, slot, p);
@@ -393,8 +398,8 @@ size_t project_target1_ws_bytes(int H, int W, int ds, int Nmax) {
 }
 int project_target1(const float *points, const int32_t *counts, int Nmax, const float *poses, const float *intrinsics, int H,
                     int W, int ds, const float *map_normals, int cap, int64_t *rows, int32_t *nrows, float *tgt, float *tnrm,
-                    int32_t *nt, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, void *ws,
-                    size_t ws_bytes, hipStream_t st) {
+                    int32_t *nt, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, int32_t *tgt_pix,
+                    void *ws, size_t ws_bytes, hipStream_t st) {
     const char *name = "gs_slam_localize/target";
     if (!ws || ws_bytes < project_target1_ws_bytes(H, W, ds, Nmax)) {
         set_error("%s: workspace too small", name);
@@ -411,7 +416,7 @@ int project_target1(const float *points, const int32_t *counts, int Nmax, const 
     if (rc) return rc;
     hipLaunchKernelGGL(pix_scan_k, dim3(1), dim3(1024), 0, st, cnt, npix, pix_start);
     hipLaunchKernelGGL(tgt_scatter_gather1_k, dim3(min(cdiv(Nmax, 256), 1024)), dim3(256), 0, st, rows, nrows, points, map_normals, cap,
-                       tgt, tnrm, nt, tgt_index, Wd, ds, pix_start, fill, scan_points, scan_orig);
+                       tgt, tnrm, nt, tgt_index, Wd, ds, pix_start, fill, scan_points, scan_orig, tgt_pix);
     GS_LAUNCH_CHECK(name);
     return GS_OK;
 }
@@ -448,7 +453,7 @@ size_t gs_bucket_by_pixel_ws_bytes(int B, int H, int W, int ds) {
 
 int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H, int W, int ds,
                        const float *map_points, int Nmax, int cap, float *scan_points, int32_t *scan_orig,
-                       int32_t *pix_start, void *ws, size_t ws_bytes, gs_stream_t stream) {
+                       int32_t *pix_start, int32_t *tgt_pix, void *ws, size_t ws_bytes, gs_stream_t stream) {
     GS_REQUIRE(rows && d_n_rows && map_points && scan_points && scan_orig && pix_start, "gs_bucket_by_pixel: NULL argument");
     GS_REQUIRE(B > 0 && B <= 256 && H > 0 && W > 0 && ds > 0 && Nmax > 0 && cap > 0 && max_rows >= 0, "gs_bucket_by_pixel: bad shape");
     if (!ws || ws_bytes < gs_bucket_by_pixel_ws_bytes(B, H, W, ds)) {
@@ -467,7 +472,7 @@ int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max
     hipLaunchKernelGGL(pix_count_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, cnt);
     hipLaunchKernelGGL(pix_scan_k, dim3(B), dim3(1024), 0, st, cnt, npix, pix_start);
     hipLaunchKernelGGL(pix_scatter_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, pix_start, fill, map_points,
-                       Nmax, cap, scan_points, scan_orig);
+                       Nmax, cap, scan_points, scan_orig, tgt_pix);
     GS_LAUNCH_CHECK("gs_bucket_by_pixel");
     return GS_OK;
 }
@@ -477,7 +482,7 @@ size_t gs_build_icp_target_ws_bytes(int B, int H, int W, int ds) { return gs_buc
 int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H, int W, int ds,
                         const float *map_points, const float *map_normals, int Nmax, int cap, float *tgt, float *tgt_normals,
                         int32_t *counts, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index,
-                        void *ws, size_t ws_bytes, gs_stream_t stream) {
+                        int32_t *tgt_pix, void *ws, size_t ws_bytes, gs_stream_t stream) {
     GS_REQUIRE(rows && d_n_rows && map_points && map_normals && tgt && tgt_normals && counts && scan_points && scan_orig && pix_start,
                "gs_build_icp_target: NULL argument");
     GS_REQUIRE(B > 0 && B <= 256 && H > 0 && W > 0 && ds > 0 && Nmax > 0 && cap > 0 && max_rows >= 0, "gs_build_icp_target: bad shape");
@@ -498,7 +503,7 @@ int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t ma
                        cap, tgt, tgt_normals, counts, Wd, npix, ds, cnt, tgt_index);
     hipLaunchKernelGGL(pix_scan_k, dim3(B), dim3(1024), 0, st, cnt, npix, pix_start);
     hipLaunchKernelGGL(pix_scatter_k, dim3(nb), dim3(256), 0, st, rows, d_n_rows, starts, Wd, npix, ds, pix_start, fill, map_points,
-                       Nmax, cap, scan_points, scan_orig);
+                       Nmax, cap, scan_points, scan_orig, tgt_pix);
     GS_LAUNCH_CHECK("gs_build_icp_target");
     return GS_OK;
 }

@@ -3,7 +3,8 @@
 Same free functions, arguments, return values and error contracts as the reference; the arithmetic
 runs in hand-written HIP kernels (gradslam_amd/csrc/icp.hip):
 
-* nearest-neighbour association: exact brute-force K=1 search (replaces chamferdist.knn_points);
+* nearest-neighbour association: exact K=1 search -- AABB-pruned, bit-identical to the brute-force scan, which
+  stays available as the verifier (replaces chamferdist.knn_points);
 * `gauss_newton_solve` rows / the fused linearise + 6x6 reduce;
 * `point_to_plane_ICP` / `point_to_plane_gradICP`: the WHOLE loop -- association, linearisation,
   6x6 solve, SE(3) exponential, LM accept/reject -- runs on the device with no host round trip
@@ -243,8 +244,18 @@ def downsample_pointclouds(pointclouds: Pointclouds, pc2im_bnhw: torch.Tensor, d
 def _gather_by_table(pointclouds: Pointclouds, table: torch.Tensor, B: int) -> Pointclouds:
     """Per batch element gather of points / normals / colours for the table rows (order kept).
     Uses torch indexing on views so gradients flow to the map (reference :600-619)."""
-    bcol = table[:, 0]
-    bounds = torch.searchsorted(bcol.contiguous(), torch.arange(B + 1, device=table.device)).tolist()
+    bcol = table[:, 0].contiguous()
+    # The tables this package builds are sorted by b (rows come out in (b, n) order); a caller's table need not be:
+    # the reference filters with `pc2im_bnhw[..., 0] == b`, which accepts any row order and keeps it within each
+    # b.  Row ranges and the sortedness flag come back in ONE host read; an unsorted table takes a stable sort.
+    edges = torch.arange(B + 1, device=table.device)
+    unsorted = (bcol[1:] < bcol[:-1]).any().view(1).to(torch.int64) if table.shape[0] > 1 else edges[:1] * 0
+    host = torch.cat([torch.searchsorted(bcol, edges), unsorted]).tolist()
+    if host[-1]:
+        order = torch.argsort(bcol, stable=True)
+        table, bcol = table[order], bcol[order]
+        host = torch.searchsorted(bcol, edges).tolist()
+    bounds = host[: B + 1]
     sel = [table[bounds[b]: bounds[b + 1], 1] for b in range(B)]
     pick = lambda xs: None if xs is None else [xs[b].index_select(0, sel[b]) for b in range(B)]
     return Pointclouds(points=pick(pointclouds.points_list), normals=pick(pointclouds.normals_list),

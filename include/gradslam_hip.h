@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 #define GS_OK 0
 #define GS_ERR_INVALID_ARG (-1)
 #define GS_ERR_WORKSPACE_TOO_SMALL (-2)
@@ -139,24 +139,26 @@ int gs_gather_table_rows(const int64_t *rows, const int32_t *d_n_rows, int64_t m
  * of each batch element by their ds-grid pixel.  scan_points (B,cap,3) = map points in pixel order,
  * scan_orig (B,cap) = rank of each of them among the rows of its batch element (the index the reference's
  * downsample_pointclouds order gives it), pix_start (B, npix+1 with npix = ceil(H/ds)*ceil(W/ds)) = first
- * scan slot of every ds-grid pixel (pix_start[npix] = number of targets).  Feeds gs_icp_hints; changes no
- * result, only the order in which the exact search visits the target. */
+ * scan slot of every ds-grid pixel (pix_start[npix] = number of targets); tgt_pix (B,cap; optional, NULL to skip) =
+ * ds-grid pixel of every row in the reference's order.  Feeds gs_icp_hints; changes no result, only the order in
+ * which the exact search visits the target. */
 size_t gs_bucket_by_pixel_ws_bytes(int B, int H, int W, int ds);
 int gs_bucket_by_pixel(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H,
                        int W, int ds, const float *map_points, int Nmax, int cap, float *scan_points,
-                       int32_t *scan_orig, int32_t *pix_start, void *ws, size_t ws_bytes,
+                       int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_pix, void *ws, size_t ws_bytes,
                        gs_stream_t stream);
 
 /* gs_gather_table_rows (points and normals) + gs_bucket_by_pixel fused into five launches: everything
  * gs_icp_point_to_plane needs of its target -- tgt / tgt_normals (B,cap,3) and counts (B) in the reference's
  * order, plus the search hints.  tgt_index (B,cap; optional, NULL to skip) receives the map index n of every
- * target slot (what the reverse pass scatters the target adjoints back with). */
+ * target slot (what the reverse pass scatters the target adjoints back with), tgt_pix (B,cap; optional) its
+ * ds-grid pixel (gs_icp_hints.tgt_pix). */
 size_t gs_build_icp_target_ws_bytes(int B, int H, int W, int ds);
 int gs_build_icp_target(const int64_t *rows, const int32_t *d_n_rows, int64_t max_rows, int B, int H,
                         int W, int ds, const float *map_points, const float *map_normals, int Nmax,
                         int cap, float *tgt, float *tgt_normals, int32_t *counts, float *scan_points,
-                        int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, void *ws,
-                        size_t ws_bytes, gs_stream_t stream);
+                        int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, int32_t *tgt_pix,
+                        void *ws, size_t ws_bytes, gs_stream_t stream);
 
 /* keep mask of downsample_pointclouds' row filter for an arbitrary table
  * (odometry/icputils.py:596-597): mask[i] = rows[i].h % ds == 0 && rows[i].w % ds == 0 */
@@ -223,10 +225,16 @@ typedef struct gs_icp_hints {
     const float *scan_points;   /* (nt,3) the target points in a spatially coherent scan order */
     const int32_t *scan_orig;   /* (nt) reference index (into tgt) of every scan slot; required with scan_points */
     const int32_t *src_pix;     /* (ns) ds-grid pixel id r*grid_w+c of every source point */
-    const int32_t *pix_start;   /* (grid_h*grid_w+1) first scan slot of every pixel (scan order = pixel order):
-                                   the FIRST association seeds every source point with the best target of the
-                                   pixels around its own (a projective guess, used as a seed only) */
+    const int32_t *pix_start;   /* (grid_h*grid_w+1) first scan slot of every pixel (scan order = pixel order) */
+    const int32_t *tgt_pix;     /* (nt) ds-grid pixel of every target, reference order (optional: lets a source point
+                                   whose neighbour has left the 3x3 pixels around its own re-centre its window) */
     int32_t grid_w, grid_h;
+    /* With scan_points, scan_orig, src_pix and pix_start all given the loops associate by GRID SEARCH WITH
+     * DISTANCE CERTIFICATES (gs_set_grid_search): every source point examines all targets of the 3x3 pixels around
+     * its window centre, and a lower bound on everything else -- established by one exact chunk-box search and
+     * carried from association to association of the loop through the triangle inequality -- proves that the
+     * window's best is the nearest neighbour; points whose proof fails take the exact search again.  Hints never
+     * change a result (tested against the brute-force scan with consistent and with scrambled hints). */
 } gs_icp_hints;
 
 /* point_to_plane_ICP (odometry/icputils.py:310-367) as one call on the device (section comment above). */
@@ -353,6 +361,13 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
  * kernel, 1 = linearise kernel. */
 void gs_profile_enable(int on);
 int gs_profile_read(int tag, long *launches, double *total_ms);
+
+/* How the loops above associate when ALL gs_icp_hints are given.  1 (default) = automatic: grid search with per-point
+ * distance certificates (see gs_icp_hints) where the target holds several points per ds-grid pixel (a map that has
+ * seen many frames), the chunk-box search otherwise; 2 = grid search whatever the density; 0 = chunk-box search
+ * always.  Same results bit for bit (all are the brute-force scan's); only the cost differs.  Replaces nothing in the
+ * reference (chamferdist.knn_points has no such switch); for measurements and tests. */
+void gs_set_grid_search(int on);
 
 /* ---------------------------------------------------------------- C+U: fusion correspondences
  * find_similar_map_points (slam/fusionutils.py:381-401): keep[i] = |Vg(b,h,w) - p(b,n)| < dist_th

@@ -890,3 +890,147 @@ def test_odd_image_shapes_vs_oracle(gs, H, W, ds, B):
         pcs, poses = slam(frames)
     assert torch.isfinite(poses).all()
     assert rel_err(poses.cpu(), oposes) < 5e-3  # small clouds: the LM loop amplifies rounding
+
+
+# ------------------------------------------------------------------ grid search with distance certificates
+def _grid_scene(seed, Hd=60, Wd=80, ds=4, per_cell=6, motion=0.004, shuffle_hints=False, duplicates=False, with_tgt_pix=True):
+    """A synthetic ds-grid scene: up to `per_cell` targets per ds-grid pixel on a wavy wall (reference order
+    shuffled, like a map), one source point per pixel with drop-outs, displaced by a small rigid motion.  Returns
+    (src, src_pix, tgt, nrm, hints tensors) on the device."""
+    g = torch.Generator().manual_seed(seed)
+    fx = 525.0 * (Wd * ds) / 640.0
+    cx, cy = (Wd * ds - 1) / 2.0, (Hd * ds - 1) / 2.0
+    wall = lambda x, y: 2.0 + 0.3 * torch.sin(2.0 * x) * torch.cos(2.0 * y)
+
+    def backproject(u, v, jitter):
+        x, y = (u - cx) / fx * 2.0, (v - cy) / fx * 2.0
+        z = wall(x, y) + jitter
+        return torch.stack([(u - cx) / fx * z, (v - cy) / fx * z, z], -1)
+
+    rr, cc = torch.meshgrid(torch.arange(Hd), torch.arange(Wd), indexing="ij")
+    cell = (rr * Wd + cc).reshape(-1)
+    n_per = torch.randint(0, per_cell + 1, (Hd * Wd,), generator=g)
+    tcell = cell.repeat_interleave(n_per)
+    nt = tcell.shape[0]
+    u = (tcell % Wd).float() * ds + (torch.rand(nt, generator=g) - 0.5)
+    v = (tcell // Wd).float() * ds + (torch.rand(nt, generator=g) - 0.5)
+    tgt = backproject(u, v, 0.002 * torch.randn(nt, generator=g))
+    if duplicates:  # exact duplicates far apart in reference index and in scan order: the lowest index must win
+        tgt[-50:] = tgt[:50]
+        tcell[-50:] = tcell[:50]
+    perm = torch.randperm(nt, generator=g)          # reference order is not image coherent
+    tgt, tcell = tgt[perm].contiguous(), tcell[perm]
+    nrm = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, -1.0]) + 0.1 * torch.randn(nt, 3, generator=g), dim=-1)
+    order = torch.argsort(tcell, stable=True)
+    pix_start = torch.zeros(Hd * Wd + 1, dtype=torch.int64)
+    pix_start[1:] = torch.cumsum(torch.bincount(tcell, minlength=Hd * Wd), 0)
+    keep = torch.rand(Hd * Wd, generator=g) > 0.08
+    sc = cell[keep]
+    src = backproject((sc % Wd).float() * ds, (sc // Wd).float() * ds, 0.001 * torch.randn(sc.shape[0], generator=g))
+    a = 0.5 * motion
+    R = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=torch.float32)
+    src = (src @ R.t() + torch.tensor([motion, -0.5 * motion, 0.3 * motion])).contiguous()
+    if shuffle_hints:  # inconsistent hints must cost speed only
+        sc = sc[torch.randperm(sc.shape[0], generator=g)]
+    dev = lambda x, dt=None: (x if dt is None else x.to(dt)).contiguous().to(DEV)
+    return dict(src=dev(src), src_pix=dev(sc, torch.int32), tgt=dev(tgt), nrm=dev(nrm.contiguous()), scan_points=dev(tgt[order]),
+                scan_orig=dev(order, torch.int32), pix_start=dev(pix_start, torch.int32),
+                tgt_pix=dev(tcell, torch.int32) if with_tgt_pix else None, Wd=Wd, Hd=Hd)
+
+
+def _taped_loop_with_hints(gs, sc, numiters, grad_lm, init_T=None):
+    """gs_icp_point_to_plane_taped through the C ABI with search hints; returns (T, [(cloud, keys) per association])."""
+    import ctypes
+
+    from gradslam_amd import _native as nv
+    from gradslam_amd import ops
+
+    class Hints(ctypes.Structure):
+        _fields_ = [("scan_points", ctypes.c_void_p), ("scan_orig", ctypes.c_void_p), ("src_pix", ctypes.c_void_p),
+                    ("pix_start", ctypes.c_void_p), ("tgt_pix", ctypes.c_void_p), ("grid_w", ctypes.c_int32), ("grid_h", ctypes.c_int32)]
+
+    h = Hints(sc["scan_points"].data_ptr(), sc["scan_orig"].data_ptr(), sc["src_pix"].data_ptr(), sc["pix_start"].data_ptr(),
+              sc["tgt_pix"].data_ptr() if sc.get("tgt_pix") is not None else None, sc["Wd"], sc["Hd"])
+    src, tgt, nrm = sc["src"], sc["tgt"], sc["nrm"]
+    ns, nt = src.shape[0], tgt.shape[0]
+    T0 = (torch.eye(4) if init_T is None else init_T).to(DEV).contiguous()
+    T = torch.empty(4, 4, device=DEV)
+    best = torch.empty(ns, dtype=torch.int64, device=DEV)
+    # (filled with junk: the loop must not depend on what a tape or workspace held before)
+    tape = torch.full((nv.ws_bytes("gs_icp_tape_bytes", ns, numiters, grad_lm),), 0xAB, dtype=torch.uint8, device=DEV)
+    ws = nv.workspace(nv.ws_bytes("gs_icp_ws_bytes", ns, nt), src.device, "icp")
+    lib = nv.lib()
+    fn = lib.gs_icp_point_to_plane_taped
+    old = list(fn.argtypes)
+    fn.argtypes = old[:16] + [ctypes.POINTER(Hints)] + old[17:]
+    d_ns, d_nt = ops.dev_int(ns, DEV), ops.dev_int(nt, DEV)  # held: a temporary's block would be reused by the next one
+    try:
+        rc = fn(src.data_ptr(), d_ns.data_ptr(), ns, tgt.data_ptr(), nrm.data_ptr(), d_nt.data_ptr(), nt,
+                T0.data_ptr(), numiters, 1e-8, -1.0, grad_lm, 2.0, 1.0, 1.0, 200.0, ctypes.byref(h), T.data_ptr(), best.data_ptr(),
+                tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), nv.stream())
+    finally:
+        fn.argtypes = old
+    assert rc == 0, lib.gs_last_error()
+    torch.cuda.synchronize()
+    # tape layout (icp.hip tape_layout): records | cloud slots | neighbour slots, everything 256-byte aligned
+    al = lambda x: (x + 255) // 256 * 256
+    n = 2 * numiters if grad_lm else numiters + 1
+    rec_b, pts_b, best_b = al((n + 1) * 160 * 4), al(ns * 12), al(ns * 8)
+    out = []
+    for a in range(n):
+        cloud = tape[rec_b + a * pts_b: rec_b + a * pts_b + ns * 12].view(torch.float32).view(ns, 3)
+        keys = tape[rec_b + n * pts_b + a * best_b: rec_b + n * pts_b + a * best_b + ns * 8].view(torch.int64)
+        out.append((cloud, keys))
+    return T, out
+
+
+@pytest.mark.parametrize("case", ["plain", "dense", "big_motion", "big_motion_dense", "big_motion_no_tgt_pix", "shuffled_hints",
+                                  "duplicates", "gradlm", "sparse", "two_rows_per_tile"])
+def test_grid_search_every_association_is_the_bruteforce_scan(gs, case):
+    """The grid search with distance certificates (knn1_loop_k<true>) must return, for EVERY association launch of a
+    loop, exactly what the brute-force scan returns on that launch's cloud: same packed (distance, index) keys.  Cases:
+    converging loop (certificates hold), dense pixels (>16 targets per pixel: several chunks per pixel), a 6 cm initial
+    offset (certificates fail, lanes leave their window), hints that do not match the geometry, exact duplicate targets
+    (lowest reference index wins), the gradLM sequence, a sparse target with empty pixels, and a grid narrower than a
+    tile (every tile spans three pixel rows)."""
+    kw = dict(plain={}, dense=dict(per_cell=40, Hd=30, Wd=40), big_motion=dict(motion=0.06),
+              big_motion_dense=dict(motion=0.05, per_cell=24, Hd=40, Wd=60), big_motion_no_tgt_pix=dict(motion=0.06, with_tgt_pix=False),
+              shuffled_hints=dict(shuffle_hints=True), duplicates=dict(duplicates=True), gradlm={}, sparse=dict(per_cell=1),
+              two_rows_per_tile=dict(Hd=90, Wd=24, motion=0.03))[case]
+    sc = _grid_scene(seed=len(case), **kw)
+    grad_lm = 1 if case == "gradlm" else 0
+    for mode in (2, 0):  # with certificates (whatever the density) / chunk boxes only: both exact, and equal to each other
+        gs._native.lib().gs_set_grid_search(mode)
+        try:
+            T, assoc = _taped_loop_with_hints(gs, sc, 6, grad_lm)
+        finally:
+            gs._native.lib().gs_set_grid_search(1)
+        for a, (cloud, keys) in enumerate(assoc):
+            want = gs.ops.knn1_raw(cloud.contiguous(), sc["tgt"], brute_force=True)
+            bad = (keys != want).sum().item()
+            assert bad == 0, (case, mode, a, bad)
+        if mode == 2:
+            T_grid = T.clone()
+    assert torch.equal(T, T_grid)
+
+
+def test_grid_search_sequence_equals_chunk_search(gs):
+    """A 25-frame PointFusion run (map and ICP target growing, several targets per pixel) with the grid search on and
+    off: poses and map bit for bit."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(1, 25, 240, 320, seed=17)
+    frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
+    out = []
+    for mode in (2, 0):
+        gs._native.lib().gs_set_grid_search(mode)
+        try:
+            for odom in ("icp", "gradicp"):
+                slam = gs.slam.PointFusion(odom=odom, dsratio=4, numiters=10, device=DEV)
+                with torch.no_grad():
+                    pcs, poses = slam(frames)
+                out.append((poses.clone(), pcs.points_list[0].clone()))
+        finally:
+            gs._native.lib().gs_set_grid_search(1)
+    for a, b in ((0, 2), (1, 3)):
+        assert torch.equal(out[a][0], out[b][0]) and torch.equal(out[a][1], out[b][1])

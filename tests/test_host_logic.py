@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_native.SIGNATURES) == names
-    assert lib.gs_abi_version() == 1
+    assert lib.gs_abi_version() == 2
 
 
 def test_integration_notes_cover_every_entry_point():

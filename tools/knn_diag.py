@@ -24,7 +24,7 @@ with torch.no_grad():
 print("src", src.shape, "tgt", tgt.shape)
 lib = _native.lib()
 nblk = 2048  # >= the association's grid for any cloud these diagnostics use (mixed 64 / 16-point tiling)
-dbg = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device=dev)
 lib.gs_diag_set_buffer.argtypes = [ctypes.c_void_p]
 for it in range(3):
     dbg.zero_()
@@ -36,7 +36,7 @@ for it in range(3):
 def report(title):
     global a
     print("====", title)
-    a = (dbg.cpu().numpy().reshape(nblk, 16, 8) & np.array([-1, -1, -1, -1, -1, 0xffff, -1, -1], dtype=np.int64)).astype(np.float64)
+    a = (dbg.cpu().numpy().reshape(nblk, 16, 16) & np.array([-1, -1, -1, -1, -1, 0xffff] + [-1] * 10, dtype=np.int64)).astype(np.float64)
     tick = 1e-2
     t0, t1, t2, t3, ns = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 4]
     g0 = t0.min()
@@ -53,7 +53,7 @@ dbg.zero_()
 T, _, _ = ops.icp_device_loop(src, tgt, nrm, torch.eye(4, device=dev), 10, 1e-8, None)
 torch.cuda.synchronize()
 report("last association of a 10-iteration ICP loop (seeded by the previous neighbour)")
-a = (dbg.cpu().numpy().reshape(nblk, 16, 8) & np.array([-1, -1, -1, -1, -1, 0xffff, -1, -1], dtype=np.int64)).astype(np.float64)
+a = (dbg.cpu().numpy().reshape(nblk, 16, 16) & np.array([-1, -1, -1, -1, -1, 0xffff] + [-1] * 10, dtype=np.int64)).astype(np.float64)
 t6, t7, t0, t3 = a[..., 6], a[..., 7], a[..., 0], a[..., 3]
 print("folded step (prologue) us per wave: p50 %.2f p99 %.2f ; prologue end -> search start p50 %.2f ; search p50 %.2f ; kernel entry spread p99 %.2f" % (
     *np.percentile((t7 - t6) * 0.01, [50, 99]), np.percentile((t0 - t7) * 0.01, 50), np.percentile((t3 - t0) * 0.01, 50),
@@ -63,14 +63,14 @@ print("kernel span incl. prologue us %.1f" % ((t3.max() - t6.min()) * 0.01))
 dbg2 = torch.zeros(8, dtype=torch.int64, device=dev)
 assert lib.gs_diag_set_buffer(dbg2.data_ptr()) == 0
 # (the association kernels also write into this buffer at other offsets: give them room)
-dbg3 = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
+dbg3 = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device=dev)
 assert lib.gs_diag_set_buffer(dbg3.data_ptr()) == 0
 T, _, _ = ops.icp_device_loop(src, tgt, nrm, torch.eye(4, device=dev), 10, 1e-8, None)
 torch.cuda.synchronize()
 st = dbg3[:8].cpu().numpy().astype(np.float64)
 print("==== last icp_step_k (us): copy-in+reduce %.2f | decide %.2f | solve6 %.2f | rest(exp, out) %.2f | total %.2f" % (
     (st[1] - st[0]) * 0.01, (st[3] - st[1]) * 0.01, (st[4] - st[3]) * 0.01, (st[2] - st[4]) * 0.01, (st[2] - st[0]) * 0.01))
-a = (dbg.cpu().numpy().reshape(nblk, 16, 8) & np.array([-1, -1, -1, -1, -1, 0xffff, -1, -1], dtype=np.int64)).astype(np.float64)
+a = (dbg.cpu().numpy().reshape(nblk, 16, 16) & np.array([-1, -1, -1, -1, -1, 0xffff] + [-1] * 10, dtype=np.int64)).astype(np.float64)
 tick = 1e-2  # wall_clock64: 100 MHz -> 10 ns per tick = 0.01 us
 t0, t1, t2, t3, ns = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 4]
 g0 = t0.min()

@@ -17,14 +17,14 @@ frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
 lib = _native.lib()
 lib.gs_diag_set_buffer.argtypes = [ctypes.c_void_p]
 nblk = 2048  # >= the association's grid (mixed 64 / 16-point tiling: 432 blocks at 19 200 candidates)
-dbg = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device=dev)
 assert lib.gs_diag_set_buffer(dbg.data_ptr()) == 0
 slam = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10, device=dev)
 with torch.no_grad():
     pcs, poses = slam(frames)
 torch.cuda.synchronize()
 print("frames", n, "map", int(pcs.num_points_per_pointcloud.item()))
-raw = dbg.cpu().numpy().reshape(nblk, 16, 8)
+raw = dbg.cpu().numpy().reshape(nblk, 16, 16)
 a = raw.astype(np.float64)
 live = a[..., 3].max(1) > 0
 a = a[live]
@@ -45,6 +45,18 @@ print("barrier wait us(per wave)  p50 %.2f p99 %.2f" % pc((t3 - t2) * tick, [50,
 print("block total us             p50 %.2f p99 %.2f max %.2f" % pc((t3.max(1) - t6.min(1)) * tick, [50, 99, 100]))
 print("kernel entry spread us p50 %.2f p99 %.2f" % pc((t6.min(1) - t6.min()) * tick, [50, 99]))
 print("kernel span us %.1f" % ((t3.max() - t6.min()) * tick))
+need = a[:, 0, 12]
+print("grid search: lanes needing the exact search per tile: mean %.2f, tiles with none %d of %d, max %d" % (need.mean(), int((need == 0).sum()), need.shape[0], int(need.max())))
+why = raw[live][:, 0, 13]
+rad = raw[live][:, 0, 14]
+worst = int(np.argmax(need))
+f = lambda w, sh: int((w >> sh) & 0xff)
+print("tile with most lanes in need (%d): not fully staged %d | smaller radius %d | no certificate %d | moved beyond radius %d | best outside reach %d ; radius %d ; "
+      "tile means (mm): sqrt(m) %.1f moved %.1f sqrt(bd) %.1f" % (need[worst], f(why[worst], 0), f(why[worst], 8), f(why[worst], 16), f(why[worst], 24), f(why[worst], 32),
+      f(why[worst], 40), (rad[worst] & 0xfffff) / 1e3, ((rad[worst] >> 20) & 0xfffff) / 1e3, ((rad[worst] >> 40) & 0xfffff) / 1e3))
+print("all tiles: lanes per reason (sum): not staged %d | radius %d | no certificate %d | moved %d | reach %d" % tuple(int(((why >> sh) & 0xff).sum()) for sh in (0, 8, 16, 24, 32)))
+print("coarse us per wave p50 %.2f p99 %.2f | fine us p50 %.2f p99 %.2f | barrier waits us p50 %.2f p99 %.2f | survivors tested per wave p50 %.0f" % (
+    *pc(a[..., 8] * tick, [50, 99]), *pc(a[..., 9] * tick, [50, 99]), *pc(a[..., 10] * tick, [50, 99]), np.percentile(a[..., 11], 50)))
 print("chunks scanned per block: mean %.1f max %d ; coarse survivors per block mean %.1f max %d" % (
     ns.sum(1).mean(), ns.sum(1).max(), a[..., 5].max(1).mean(), a[..., 5].max(1).max()))
 ml = ((t2 - t1) * tick).max(1)
