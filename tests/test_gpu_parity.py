@@ -224,9 +224,12 @@ def test_icp_device_loop_vs_reference_trace(gs, golden, case, kw):
     n = kw["numiters"]
     # per-iteration LM state against the reference's own trace
     # errors are compared down to 1e-8 of the first one: a converged residual (~1e-10) is rounding noise.
-    # With a distance threshold, points cross it under 1e-7 pose differences and the residual sum moves in
-    # steps (any change of the reduction order shows): first iterations tight, the rest to 1e-2; without a
-    # threshold the sums agree to 1e-4 throughout.  The final transform is always held to 1e-4.
+    # With a distance threshold that points actually cross (fix_icp: 0.2), the residual sum moves in steps under ANY
+    # 1e-7-level change: tools/trace_attribution.py replays the CPU oracle on this case with the 6x6 system solved in
+    # fp64, with A^T A summed in fp64, and with the source nudged by 1e-7 -- err / new_err of the late iterations move
+    # by 5e-3 / 7e-3 / 3.5e-1 respectively while the final transform stays within 2.4e-7.  So:
+    # first iterations tight, the rest to 1e-2 there; without crossings the sums agree to 1e-4 throughout (the same
+    # three variants move them by <= 1.5e-6).  The final transform is always held to 1e-4.
     atol = 1e-8 * float(g[case + "_err"][0])
     rtol = 1e-4 if kw["dist_thresh"] is None else 1e-2
     np.testing.assert_allclose(trace[:3, 42], g[case + "_err"][:3], rtol=1e-4, atol=atol)
@@ -464,50 +467,87 @@ def test_unique_tiebreak_handmade(gs):
 
 
 # ------------------------------------------------------------------ config 1 end to end (+ gradients)
-@pytest.mark.parametrize("name,cls,odom", [("pf_gt", "PointFusion", "gt"), ("pf_icp", "PointFusion", "icp"),
-                                           ("pf_gradicp", "PointFusion", "gradicp"), ("is_gradicp", "ICPSLAM", "gradicp")])
-def test_config1_forward_vs_reference(gs, golden, name, cls, odom):
-    g = golden("ref_slam_c1")
+# Tolerances = what tools/parity_probe.py measures on an MI355X plus a margin (profiles/r02_parity_probe.txt):
+#   poses 0 (gt) / 2e-8 (icp) / 1.2e-6 (gradicp) relative; map sizes exact; attributes <= 7e-7;
+#   gradients of colours and poses <= 4e-7; depth gradients equal to 1e-4 of their maximum except on <= 5 pixels
+#   (the dh == dv stencils of DESIGN.md "sensitivity", where the reference's normal is a rounding residue);
+#   intrinsics gradients -- sums over ALL pixels, those few included -- 1.2e-2 at 64x64, 6e-4 at 160x120.
+# For scale: the reference's OWN outputs move by 6.6e-5 (poses), 1e-3 (intrinsics gradient) and 5-20 % (depth
+# gradient, maximum norm) when its depth input is perturbed by 1e-7 relative (tools/gen_golden_c1b.py --sensitivity).
+C1_CASES = [("pf_gt", "PointFusion", "gt"), ("pf_icp", "PointFusion", "icp"), ("pf_gradicp", "PointFusion", "gradicp"),
+            ("is_gradicp", "ICPSLAM", "gradicp")]
+
+
+def _c1_inputs(g):
+    if "colors" in g:
+        c = t(g["colors"])
+    else:  # ref_slam_c1b: the colours are regenerated (uniform noise does not compress) and pinned by a checksum
+        from gradslam_amd.synthetic import make_sequence
+
+        L, H, W, seed = (int(x) for x in g["shape"])
+        c = make_sequence(1, L, H, W, seed=seed)[0]
+        assert float(c.double().sum()) == float(g["colors_sum"][0])
+    return c, t(g["depths"]), t(g["intrinsics"]), t(g["poses"])
+
+
+def _check_map(pcs, g, name, tol):
+    st = int(g[name + "_map_stride"][0]) if name + "_map_stride" in g else 1
+    n_ref = int(g[name + "_map_count"][0]) if name + "_map_count" in g else g[name + "_map_points_0"].shape[0]
+    assert pcs.points_list[0].shape[0] == n_ref, (name, pcs.points_list[0].shape[0], n_ref)
+    for attr, key in (("points_list", "points"), ("normals_list", "normals"), ("colors_list", "colors")):
+        e = rel_err(getattr(pcs, attr)[0].detach().cpu()[::st], g[f"{name}_map_{key}_0"])
+        assert e < tol, (name, key, e)
+    if name + "_map_feats_0" in g:
+        e = rel_err(pcs.features_list[0].detach().cpu(), g[name + "_map_feats_0"])
+        assert e < tol, (name, "feats", e)
+
+
+@pytest.mark.parametrize("gname", ["ref_slam_c1", "ref_slam_c1b"])
+@pytest.mark.parametrize("name,cls,odom", C1_CASES)
+def test_config1_forward_vs_reference(gs, golden, gname, name, cls, odom):
+    """BASELINE config 1 (2-frame 64x64) and its 3-frame 160x120 sibling against the REFERENCE's outputs: poses to 1e-5
+    (north_star asks 1e-4; measured <= 1.2e-6), the map size exactly, every fused attribute to 1e-5 (measured <= 7e-7)."""
+    g = golden(gname)
+    if name + "_poses" not in g:
+        pytest.skip("case not in this golden")
+    c, dd, K, P = _c1_inputs(g)
     slam = getattr(gs.slam, cls)(odom=odom, dsratio=4, numiters=10, device=DEV)
     with torch.no_grad():
-        pcs, poses = slam(gs.RGBDImages(d(g["colors"]), d(g["depths"]), d(g["intrinsics"]), d(g["poses"])))
-    ref_poses = g[name + "_poses"]
-    err = rel_err(poses.cpu(), ref_poses)
-    print(name, "pose rel err", err)
-    # 64x64 / ds=4 leaves <=256 ICP points: the loop is chaotic (DESIGN.md "sensitivity"); poses agree
-    # to 1e-4 relative without ICP and to 5e-3 with it on this toy size
-    assert err < (1e-5 if odom == "gt" else 5e-3)
-    assert abs(pcs.points_list[0].shape[0] - g[name + "_map_points_0"].shape[0]) <= (0 if odom == "gt" else 40)
-    if odom == "gt":
-        for attr, key in (("points_list", "points"), ("normals_list", "normals"), ("colors_list", "colors")):
-            assert rel_err(getattr(pcs, attr)[0].cpu(), g[f"{name}_map_{key}_0"]) < 1e-5
-        if cls == "PointFusion":
-            assert rel_err(pcs.features_list[0].cpu(), g[name + "_map_feats_0"]) < 1e-5
+        pcs, poses = slam(gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV)))
+    err = rel_err(poses.cpu(), g[name + "_poses"])
+    print(gname, name, "pose rel err", err)
+    assert err < 1e-5, (name, err)
+    _check_map(pcs, g, name, 1e-5)
 
 
-def test_config1_gradients_gt(gs, golden):
-    g = golden("ref_slam_c1")
-    c, dd, K, P = (d(g[k]).clone().requires_grad_(True) for k in ("colors", "depths", "intrinsics", "poses"))
-    slam = gs.slam.PointFusion(odom="gt", dsratio=4, numiters=10, device=DEV)
+@pytest.mark.parametrize("gname", ["ref_slam_c1", "ref_slam_c1b"])
+@pytest.mark.parametrize("name,cls,odom", C1_CASES)
+def test_config1_gradients_vs_reference(gs, golden, gname, name, cls, odom):
+    """All four input gradients of  poses.sum() + points.sum() + colors.mean()  against the reference's own autograd,
+    with and without ICP in the graph (tolerances: see the comment above C1_CASES)."""
+    g = golden(gname)
+    if name + "_poses" not in g:
+        pytest.skip("case not in this golden")
+    c, dd, K, P = (x.to(DEV).clone().requires_grad_(True) for x in _c1_inputs(g))
+    slam = getattr(gs.slam, cls)(odom=odom, dsratio=4, numiters=10, device=DEV)
     pcs, poses = slam(gs.RGBDImages(c, dd, K, P))
     (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
-    for k, x in (("colors", c), ("depths", dd), ("intrinsics", K), ("poses", P)):
-        got = x.grad.cpu() if x.grad is not None else torch.zeros(x.shape)
-        e = rel_err(got, g[f"pf_gt_grad_{k}"])
-        print(k, e)
-        assert e < 2e-4, k
-
-
-def test_config1_gradients_flow_through_icp(gs, golden):
-    g = golden("ref_slam_c1")
-    c, dd, K, P = (d(g[k]).clone().requires_grad_(True) for k in ("colors", "depths", "intrinsics", "poses"))
-    slam = gs.slam.PointFusion(odom="gradicp", dsratio=4, numiters=10, device=DEV)
-    pcs, poses = slam(gs.RGBDImages(c, dd, K, P))
-    (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
-    for k, x in (("colors", c), ("depths", dd), ("intrinsics", K), ("poses", P)):
-        assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0, k
-    # chaotic through 10 ICP iterations on <=256 points: compare loosely
-    assert rel_err(dd.grad.cpu(), g["pf_gradicp_grad_depths"]) < 0.5
+    assert rel_err(poses.detach().cpu(), g[name + "_poses"]) < 1e-5
+    _check_map(pcs, g, name, 1e-5)  # the differentiable (staged mapping) path builds the same map
+    grads = {k: (x.grad.cpu() if x.grad is not None else torch.zeros(x.shape)) for k, x in
+             (("colors", c), ("depths", dd), ("intrinsics", K), ("poses", P))}
+    for k in ("colors", "poses"):
+        e = rel_err(grads[k], g[f"{name}_grad_{k}"])
+        assert e < 1e-5, (name, k, e)
+    ref = t(g[f"{name}_grad_depths"]).double()
+    off = ((grads["depths"].double() - ref).abs() > 1e-4 * ref.abs().max()).sum().item()
+    e_d = rel_err(grads["depths"], ref)
+    print(gname, name, "depth gradient: elements off by > 1e-4 of the maximum:", off, "max rel err", e_d)
+    assert off <= (0 if odom == "gt" else 12), (name, "depths", off)          # measured: 0 / <= 5
+    assert e_d < (1e-5 if odom == "gt" else 0.1), (name, "depths", e_d)         # measured: 4e-6 / <= 2.7e-2 (those pixels)
+    e_k = rel_err(grads["intrinsics"], g[f"{name}_grad_intrinsics"])
+    tol_k = 1e-5 if odom == "gt" else (5e-2 if gname == "ref_slam_c1" else 5e-3)  # measured: 1e-7 / 1.2e-2 / 6e-4
+    assert e_k < tol_k, (name, "intrinsics", e_k, "the reference's own value moves by ~1e-3 under a 1e-7 depth perturbation")
 
 
 # ------------------------------------------------------------------ BASELINE size vs the oracle
@@ -1034,3 +1074,136 @@ def test_grid_search_sequence_equals_chunk_search(gs):
             gs._native.lib().gs_set_grid_search(1)
     for a, b in ((0, 2), (1, 3)):
         assert torch.equal(out[a][0], out[b][0]) and torch.equal(out[a][1], out[b][1])
+
+
+# ------------------------------------------------------------------ BASELINE configs 3 and 4 at full image size
+def test_config3_forward_backward_vs_oracle_640x480(gs):
+    """BASELINE configs[2] ("c3": PointFusion, 640x480, forward + backward) at reduced length (L = 3, the CPU oracle's
+    autograd takes seconds per frame): recovered poses, map size, and ALL FOUR input gradients of
+    poses.sum() + points.sum() + colors.mean() against the oracle's torch-CPU autograd (the oracle itself is pinned to
+    the reference's gradients at 64x64 and 160x120 by tests/test_oracle_golden.py).  reference: slam/pointfusion.py:107-112,
+    slam/fusionutils.py:654-720, odometry/icputils.py:479-545 under torch autograd."""
+    from gradslam_amd.synthetic import make_sequence
+    from oracle import slam as oslam
+
+    c0, d0, K0, P0 = make_sequence(1, 3, 480, 640, seed=3)
+    oc, od, oK, oP = (x.clone().requires_grad_(True) for x in (c0, d0, K0, P0))
+    ocloud, oposes = oslam.run(oc, od, oK, oP, mode="pointfusion", odom="gradicp", dsratio=4, numiters=10)
+    (oposes.sum() + ocloud.padded("points").sum() + ocloud.padded("colors").mean()).backward()
+    c, dd, K, P = (x.to(DEV).clone().requires_grad_(True) for x in (c0, d0, K0, P0))
+    slam = gs.slam.PointFusion(odom="gradicp", dsratio=4, numiters=10, device=DEV)
+    pcs, poses = slam(gs.RGBDImages(c, dd, K, P))
+    (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
+    perr = rel_err(poses.detach().cpu(), oposes.detach())
+    n, on = int(pcs.num_points_per_pointcloud.item()), ocloud.counts[0]
+    print("c3 fwd+bwd: pose rel err", perr, "map", n, "oracle", on)
+    assert perr < 1e-4
+    assert abs(n - on) <= max(20, on // 5000)   # a few pixels fall on the other side of the 5 cm / 20 degree thresholds
+    same_map = n == on
+    for k, x, ox in (("colors", c, oc), ("depths", dd, od), ("intrinsics", K, oK), ("poses", P, oP)):
+        got, ref = x.grad.cpu().double(), ox.grad.double()
+        assert torch.isfinite(got).all(), k
+        off = ((got - ref).abs() > 1e-3 * ref.abs().max()).double().mean().item()
+        print("   grad", k, "max rel err %.2e" % rel_err(got, ref), "fraction of elements off by > 1e-3 of the maximum: %.1e" % off)
+        if k in ("colors", "depths"):
+            # per-pixel gradients: equal but for the pixels whose fusion decision differs (the map sizes above) and the
+            # degenerate normal stencils (DESIGN.md "sensitivity")
+            assert off < (1e-4 if same_map else 1e-3), (k, off)
+        else:
+            assert rel_err(got, ref) < 5e-3, (k, rel_err(got, ref))
+
+
+def test_config4_batch_of_eight_equals_eight_single_runs(gs):
+    """BASELINE configs[3] ("c4") shape: PointFusion on B = 8 independent 640x480 sequences.  Sequences never interact
+    (one per GPU in deployment): the batched run must equal eight single-sequence runs bit for bit -- poses, map sizes
+    and every map attribute -- on the streamed driver and through step()."""
+    from gradslam_amd.synthetic import make_sequence
+
+    B, L = 8, 3
+    c, dd, K, P = make_sequence(B, L, 480, 640, seed=40)
+    run = lambda sl, streamed: _run_pf(gs, c[sl], dd[sl], K[sl], P[sl], streamed)
+    for streamed in (True, False):
+        pcs, poses = run(slice(0, B), streamed)
+        assert rel_err(poses.cpu(), P) < 2e-2
+        for b in range(B):
+            spcs, sposes = run(slice(b, b + 1), streamed)
+            assert torch.equal(poses[b], sposes[0]), (streamed, b)
+            for attr in ("points_list", "normals_list", "colors_list", "features_list"):
+                assert torch.equal(getattr(pcs, attr)[b], getattr(spcs, attr)[0]), (streamed, b, attr)
+
+
+def _run_pf(gs, c, dd, K, P, streamed):
+    slam = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10, device=DEV)
+    slam.streamed = streamed
+    with torch.no_grad():
+        return slam(gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV)))
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    """One rank of the world-size-2 rehearsal: real PointFusion on this rank's shard through run_sharded (gloo; both
+    ranks share the one card of the test box)."""
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import gradslam_amd as gsm
+    from gradslam_amd import parallel
+    from gradslam_amd.synthetic import make_sequence
+
+    parallel.init_from_env(backend="gloo")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c, dd, K, P = (x.to(dev) for x in make_sequence(3, 3, 120, 160, seed=50))
+
+    def slam_fn(cs, ds, ks, ps):
+        slam = gsm.slam.PointFusion(odom="icp", dsratio=2, numiters=5, device=dev)
+        with torch.no_grad():
+            return slam(gsm.RGBDImages(cs, ds, ks, ps))
+
+    _, poses, maps = parallel.run_sharded(slam_fn, c, dd, K, P, gather_maps=True)
+    torch.save({"poses": poses.cpu(), "maps": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in maps.items()}},
+               os.path.join(out_dir, "r{}.pt".format(rank)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_run_sharded_real_slam_two_ranks(gs, tmp_path):
+    """Multi-rank path with the REAL kernels: B = 3 sequences sharded 2 + 1 over two ranks, PointFusion per rank, final
+    gather of poses and of the full maps (all four attributes) -- equal on every rank to the unsharded batch, in the
+    reference's padded layout (structures/pointclouds.py:960-995)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from gradslam_amd.synthetic import make_sequence
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c, dd, K, P = make_sequence(3, 3, 120, 160, seed=50)
+    slam = gs.slam.PointFusion(odom="icp", dsratio=2, numiters=5, device=DEV)
+    with torch.no_grad():
+        pcs, poses = slam(gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV)))
+    for r in range(2):
+        o = torch.load(str(tmp_path / "r{}.pt".format(r)))
+        assert torch.equal(o["poses"], poses.cpu())
+        assert o["maps"]["counts"] == pcs.num_points_per_pointcloud.tolist()
+        for key, want in (("points", pcs.points_padded), ("normals", pcs.normals_padded), ("colors", pcs.colors_padded),
+                          ("features", pcs.features_padded)):
+            assert torch.equal(o["maps"][key], want.cpu()), key
+
+
+def test_downsample_pointclouds_accepts_an_unsorted_table(gs, golden):
+    """The reference filters rows with `pc2im_bnhw[..., 0] == b` (odometry/icputils.py:600-619): any row order is
+    accepted and kept within each batch element.  A table shuffled across batch elements must give the sorted one's rows."""
+    g = golden("msrd_b2s3")
+    frames = frames_from(g, gs)
+    fu = gs.slam.fusionutils
+    pc = fu.update_map_fusion(gs.Pointclouds(device=DEV), frames[:, 0], 0.05, math.cos(math.radians(20)), 0.6)
+    tab = fu.find_active_map_points(pc, frames[:, 0])
+    ref = gs.odometry.icputils.downsample_pointclouds(pc, tab, 4)
+    perm = torch.randperm(tab.shape[0], generator=torch.Generator().manual_seed(0)).to(DEV)
+    shuffled = tab[perm]
+    got = gs.odometry.icputils.downsample_pointclouds(pc, shuffled, 4)
+    for b in range(2):
+        # same rows per batch element, in the shuffled table's own order
+        keep = shuffled[(shuffled[:, 0] == b) & (shuffled[:, 2] % 4 == 0) & (shuffled[:, 3] % 4 == 0)][:, 1]
+        assert torch.equal(got.points_list[b], pc.points_list[b][keep])
+        assert got.points_list[b].shape == ref.points_list[b].shape

@@ -380,3 +380,20 @@ def test_recorded_bench_line_follows_the_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+def test_require_hip_rejects_tensors_of_another_device(monkeypatch):
+    """The C ABI takes raw pointers and the CURRENT device's stream: a tensor on another device must raise before any
+    launch.  No GPU here: tensors are stand-ins with the two attributes the guard reads."""
+    class _T:
+        def __init__(self, index):
+            self.is_cuda, self.device = True, torch.device("cuda", index)
+
+    monkeypatch.setattr(_native, "_raw_device", lambda: 0)
+    _native.require_hip(_T(0), None, _T(0), op="probe")
+    with pytest.raises(RuntimeError, match=r"current HIP device is cuda:0.*set_device\(1\)"):
+        _native.require_hip(_T(0), _T(1), op="probe")
+    monkeypatch.setattr(_native, "_raw_device", lambda: 1)
+    _native.require_hip(_T(1), op="probe")
+    with pytest.raises(RuntimeError, match="tensor is on cuda:0"):
+        _native.require_hip(_T(0), op="probe")

@@ -188,3 +188,32 @@ def test_config1_slam_and_gradients(golden, name, mode, odom):
         # DESIGN.md "sensitivity").  Without ICP in the graph the bound is tight.
         tol = 1e-4 if odom == "gt" else 5e-2
         assert rel_err(got, ref) < tol, (k, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("name,mode,odom", [("pf_icp", "pointfusion", "icp"), ("pf_gradicp", "pointfusion", "gradicp"),
+                                            ("is_gradicp", "icpslam", "gradicp")])
+def test_config1b_slam_and_gradients(golden, name, mode, odom):
+    """The 3-frame 160x120 sibling of config 1 (tools/gen_golden_c1b.py: 1 200 ICP points, less chaotic): the oracle
+    against the reference's poses, map and input gradients."""
+    from gradslam_amd.synthetic import make_sequence
+
+    g = golden("ref_slam_c1b")
+    L, H, W, seed = (int(x) for x in g["shape"])
+    c0 = make_sequence(1, L, H, W, seed=seed)[0]
+    assert float(c0.double().sum()) == float(g["colors_sum"][0])
+    c, d, K, P = (x.clone().requires_grad_(True) for x in (c0, t(g["depths"]), t(g["intrinsics"]), t(g["poses"])))
+    cloud, poses = slam.run(c, d, K, P, mode=mode, odom=odom, dsratio=4, numiters=10)
+    assert rel_err(poses.detach(), g[name + "_poses"]) < 1e-5
+    st = int(g[name + "_map_stride"][0])
+    assert cloud.counts == [int(g[name + "_map_count"][0])]
+    for attr, key in (("points", "points"), ("normals", "normals"), ("colors", "colors")):
+        assert rel_err(getattr(cloud, attr)[0].detach()[::st], g[f"{name}_map_{key}_0"]) < 1e-5, attr
+    loss = poses.sum() + cloud.padded("points").sum() + cloud.padded("colors").mean()
+    loss.backward()
+    for k, x in (("colors", c), ("depths", d), ("intrinsics", K), ("poses", P)):
+        ref = t(g[f"{name}_grad_{k}"]).double()
+        got = (x.grad if x.grad is not None else torch.zeros_like(x)).double()
+        if k == "depths":  # a handful of degenerate-stencil pixels carry rounding-residue gradients (DESIGN.md "sensitivity")
+            assert ((got - ref).abs() > 1e-3 * ref.abs().max()).sum().item() <= 16
+        else:
+            assert rel_err(got, ref) < 5e-3, (k, rel_err(got, ref))

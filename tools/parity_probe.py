@@ -60,7 +60,10 @@ for gname in ("ref_slam_c1", "ref_slam_c1b"):
             for k, x in (("colors", cc), ("depths", dd), ("intrinsics", kk), ("poses", pp)):
                 got = x.grad if x.grad is not None else torch.zeros_like(x)
                 ref = g[f"{name}_grad_{k}"]
-                line += " | g_%s %.1e (off>1e-3: %.1e)" % (k, rel(got, ref), frac_off(got, ref, 1e-3))
+                n_el = ref.size
+                line += " | g_%s %.1e (elements off by >1e-3/1e-4/1e-5 of max: %d/%d/%d of %d)" % (
+                    k, rel(got, ref), round(frac_off(got, ref, 1e-3) * n_el), round(frac_off(got, ref, 1e-4) * n_el),
+                    round(frac_off(got, ref, 1e-5) * n_el), n_el)
             print(line, flush=True)
         with torch.no_grad():
             slam = getattr(gs.slam, cls)(odom=odom, dsratio=4, numiters=10, device=DEV)
