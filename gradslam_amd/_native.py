@@ -79,7 +79,13 @@ SIGNATURES = {
                                      c_f, c_f, c_p, c_p, c_sz, c_p, c_sz, c_p]),
     "gs_slam_localize_backward_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "gs_slam_localize_backward": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_sz,
-                                        c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+                                        c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "gs_pointfusion_update_tape_bytes": (c_sz, [c_i, c_i, c_i]),
+    "gs_pointfusion_update_taped": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_p, c_p,
+                                          c_sz, c_p, c_sz, c_p]),
+    "gs_pointfusion_update_backward_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "gs_pointfusion_update_backward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_sz,
+                                             c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "gs_compose_poses": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "gs_set_graph_mode": (None, [c_i]),
     "gs_graph_stats": (c_i, [ctypes.POINTER(ctypes.c_double)]),

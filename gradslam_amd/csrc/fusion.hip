@@ -255,6 +255,81 @@ __global__ void merge_bwd_k(const int *__restrict__ match_pix, const int32_t *__
     }
 }
 
+// ------------------------------------------------------------------ differentiable arena update (one node per sequence)
+// Tape of one in-place PointFusion update: what the reverse pass cannot recompute once later frames have changed the
+// arena -- the per-pixel winner (which map point every pixel merged into; none: the pixel was appended if its depth
+// is valid) and the ten attribute floats that map point held BEFORE the merge.
+__global__ void tape_old_k(const unsigned int *__restrict__ pix_n, int64_t npix, int HW, int Nmax, const float *__restrict__ p,
+                           const float *__restrict__ nn, const float *__restrict__ cl, const float *__restrict__ cc,
+                           unsigned int *__restrict__ t_pix_n, float *__restrict__ t_old /* (npix, 10) */) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int n = pix_n[i];
+        t_pix_n[i] = n;
+        if (n == 0xffffffffu) continue;
+        const int64_t pt = (i / HW) * (int64_t)Nmax + n;
+        const f3 x = ld3(p, pt), y = ld3(nn, pt), z = ld3(cl, pt);
+        float *o = t_old + 10 * i;
+        o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = y.x; o[4] = y.y; o[5] = y.z; o[6] = z.x; o[7] = z.y; o[8] = z.z; o[9] = cc[pt];
+    }
+}
+// Reverse of the merge for the matched pixels (the formulas of merge_bwd_k; an UNMATCHED map point passes its
+// adjoint through unchanged -- x' = (c x + 0) / c -- so nothing is done for it: the pass costs O(pixels), not O(map)):
+// the map point's adjoint G is pulled back in place, the frame's adjoints are written (one map point per pixel: plain
+// stores), and the arena row gets its pre-merge values back, so that the arena is the map of the previous frame again
+// when the reverse pass moves on.
+__global__ void fuse_bwd_matched_k(const unsigned int *__restrict__ t_pix_n, const float *__restrict__ t_old, int64_t npix, int HW,
+                                   int Nmax, const float *__restrict__ gv, const float *__restrict__ gn, const float *__restrict__ rgb,
+                                   const float *__restrict__ alpha, float *__restrict__ p, float *__restrict__ nn,
+                                   float *__restrict__ cl, float *__restrict__ cc, float *__restrict__ Gp, float *__restrict__ Gn,
+                                   float *__restrict__ Gc, float *__restrict__ Gcc, float *__restrict__ ggv, float *__restrict__ ggn,
+                                   float *__restrict__ grgb, float *__restrict__ galpha) {
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int n = t_pix_n[pix];
+        if (n == 0xffffffffu) continue;
+        const int64_t pt = (pix / HW) * (int64_t)Nmax + n;
+        const float *o = t_old + 10 * pix;
+        const f3 x{o[0], o[1], o[2]}, y{o[3], o[4], o[5]}, z{o[6], o[7], o[8]};
+        const float c = o[9], a = alpha[pix];
+        const f3 fp = ld3(gv, pix), fn = ld3(gn, pix), fc = ld3(rgb, pix);
+        const float c2 = c + a;
+        const float inv = 1.0f / (c2 == 0.0f ? 1.0f : c2), dinv = (c2 == 0.0f) ? 0.0f : 1.0f;
+        const f3 gx = ld3(Gp, pt), gy = ld3(Gn, pt), gz = ld3(Gc, pt);
+        const float gc2 = Gcc[pt];
+        const f3 xo{((c * x.x) + (a * fp.x)) * inv, ((c * x.y) + (a * fp.y)) * inv, ((c * x.z) + (a * fp.z)) * inv};
+        const f3 yo{((c * y.x) + (a * fn.x)) * inv, ((c * y.y) + (a * fn.y)) * inv, ((c * y.z) + (a * fn.z)) * inv};
+        const f3 zo{((c * z.x) + (a * fc.x)) * inv, ((c * z.y) + (a * fc.y)) * inv, ((c * z.z) + (a * fc.z)) * inv};
+        const float s_out = (xo.x * gx.x + xo.y * gx.y + xo.z * gx.z) + (yo.x * gy.x + yo.y * gy.y + yo.z * gy.z) +
+                            (zo.x * gz.x + zo.y * gz.y + zo.z * gz.z);
+        const float s_in = (x.x * gx.x + x.y * gx.y + x.z * gx.z) + (y.x * gy.x + y.y * gy.y + y.z * gy.z) +
+                           (z.x * gz.x + z.y * gz.y + z.z * gz.z);
+        const float s_f = (fp.x * gx.x + fp.y * gx.y + fp.z * gx.z) + (fn.x * gy.x + fn.y * gy.y + fn.z * gy.z) +
+                          (fc.x * gz.x + fc.y * gz.y + fc.z * gz.z);
+        st3(Gp, pt, f3{c * inv * gx.x, c * inv * gx.y, c * inv * gx.z});
+        st3(Gn, pt, f3{c * inv * gy.x, c * inv * gy.y, c * inv * gy.z});
+        st3(Gc, pt, f3{c * inv * gz.x, c * inv * gz.y, c * inv * gz.z});
+        Gcc[pt] = gc2 + (s_in - dinv * s_out) * inv;
+        st3(ggv, pix, f3{a * inv * gx.x, a * inv * gx.y, a * inv * gx.z});
+        st3(ggn, pix, f3{a * inv * gy.x, a * inv * gy.y, a * inv * gy.z});
+        st3(grgb, pix, f3{a * inv * gz.x, a * inv * gz.y, a * inv * gz.z});
+        galpha[pix] = gc2 + (s_f - dinv * s_out) * inv;
+        st3(p, pt, x); st3(nn, pt, y); st3(cl, pt, z); cc[pt] = c;  // the arena row as it was before this frame
+    }
+}
+// appended rows: row base + k of the arena is the k-th unmatched valid pixel in row-major order -- the adjoint of the
+// append is the same compaction run backwards (the writer reads where AppendWriter wrote)
+struct AppendBwdWriter {
+    const float *G[4];
+    float *out[4];
+    int words[4];
+    const int32_t *base;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int64_t at = (int64_t)(*base) + pos;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            for (int w = 0; w < words[a]; ++w) out[a][(int64_t)words[a] * i + w] = G[a][(int64_t)words[a] * at + w];
+    }
+};
+
 // ------------------------------------------------------------------ A
 __global__ void valid_mask_k(const float *__restrict__ depth, int64_t n, uint8_t *__restrict__ mask) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -423,6 +498,75 @@ int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const
     if (rc) return rc;
     hipLaunchKernelGGL(append_count_k, dim3(1), dim3(64), 0, st, d_count, total, cap, d_appended, d_overflow);
     GS_LAUNCH_CHECK("gs_pointfusion_update/append count");
+    return GS_OK;
+}
+size_t fusion_tape_bytes(int B, int H, int W) {
+    const size_t npix = (size_t)B * H * W;
+    return 2 * align_up((size_t)B * 4, 256) + align_up(npix * 4, 256) + align_up(npix * 40, 256);
+}
+struct FusionTape {
+    int32_t *n_before, *appended;
+    unsigned int *pix_n;
+    float *old;
+};
+static inline FusionTape fusion_tape_ptrs(void *tape, int B, int H, int W) {
+    const size_t npix = (size_t)B * H * W;
+    char *p = (char *)tape;
+    FusionTape t;
+    t.n_before = (int32_t *)p; p += align_up((size_t)B * 4, 256);
+    t.appended = (int32_t *)p; p += align_up((size_t)B * 4, 256);
+    t.pix_n = (unsigned int *)p; p += align_up(npix * 4, 256);
+    t.old = (float *)p;
+    return t;
+}
+// after fusion_unique_match, before the merge: winners, pre-merge values and the row counts before the append
+int fusion_tape_record(const void *state, void *tape, int B, int H, int W, int Nmax, const int32_t *counts, const float *points,
+                       const float *normals, const float *colors, const float *ccounts, hipStream_t st) {
+    unsigned long long *pix_key; unsigned int *pix_n; int *match;
+    fusion_state_ptrs((void *)state, B, H, W, &pix_key, &pix_n, &match);
+    const FusionTape t = fusion_tape_ptrs(tape, B, H, W);
+    const int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(tape_old_k, dim3(grid1d(npix)), dim3(256), 0, st, (const unsigned int *)pix_n, npix, H * W, Nmax, points, normals,
+                       colors, ccounts, t.pix_n, t.old);
+    GS_LAUNCH_CHECK("gs_pointfusion_update_taped/record");
+    GS_HIP(hipMemcpyAsync(t.n_before, counts, (size_t)B * 4, hipMemcpyDeviceToDevice, st), "gs_pointfusion_update_taped/counts");
+    return GS_OK;
+}
+int fusion_tape_appended(void *tape, int B, int H, int W, const int32_t *appended, hipStream_t st) {
+    const FusionTape t = fusion_tape_ptrs(tape, B, H, W);
+    GS_HIP(hipMemcpyAsync(t.appended, appended, (size_t)B * 4, hipMemcpyDeviceToDevice, st), "gs_pointfusion_update_taped/appended");
+    return GS_OK;
+}
+// reverse of merge + append for one frame (see fuse_bwd_matched_k): frame adjoints fully written, G pulled back in
+// place, arena rows and counts restored to the previous frame's
+int fusion_update_reverse(const void *tape, int B, int H, int W, int Nmax, const float *depth, const float *gvertex,
+                          const float *gnormal, const float *rgb, const float *alpha, float *points, float *normals, float *colors,
+                          float *ccounts, int32_t *counts, float *Gp, float *Gn, float *Gc, float *Gcc, float *g_gvertex,
+                          float *g_gnormal, float *g_rgb, float *g_alpha, void *cws, hipStream_t st) {
+    const char *name = "gs_pointfusion_update_backward";
+    const FusionTape t = fusion_tape_ptrs((void *)tape, B, H, W);
+    const int64_t npix = (int64_t)B * H * W, HW = (int64_t)H * W;
+    GS_HIP(hipMemsetAsync(g_gvertex, 0, npix * 12, st), name);
+    GS_HIP(hipMemsetAsync(g_gnormal, 0, npix * 12, st), name);
+    GS_HIP(hipMemsetAsync(g_rgb, 0, npix * 12, st), name);
+    GS_HIP(hipMemsetAsync(g_alpha, 0, npix * 4, st), name);
+    for (int b = 0; b < B; ++b) {  // appended pixels: their rows sit behind n_before[b]
+        AppendBwdWriter wr;
+        const float *G[4] = {Gp + (size_t)b * Nmax * 3, Gn + (size_t)b * Nmax * 3, Gc + (size_t)b * Nmax * 3, Gcc + (size_t)b * Nmax};
+        float *out[4] = {g_gvertex + b * HW * 3, g_gnormal + b * HW * 3, g_rgb + b * HW * 3, g_alpha + b * HW};
+        const int words[4] = {3, 3, 3, 1};
+        for (int a = 0; a < 4; ++a) { wr.G[a] = G[a]; wr.out[a] = out[a]; wr.words[a] = words[a]; }
+        wr.base = t.n_before + b;
+        int *total = (int *)((char *)cws + compact_ws_bytes(HW));
+        AppendPredPix pred{depth + b * HW, t.pix_n + b * HW};
+        const int rc = compact_launch(HW, pred, wr, total, cws, st, name);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(fuse_bwd_matched_k, dim3(grid1d(npix)), dim3(256), 0, st, (const unsigned int *)t.pix_n, (const float *)t.old, npix,
+                       H * W, Nmax, gvertex, gnormal, rgb, alpha, points, normals, colors, ccounts, Gp, Gn, Gc, Gcc, g_gvertex, g_gnormal,
+                       g_rgb, g_alpha);
+    GS_LAUNCH_CHECK(name);
+    GS_HIP(hipMemcpyAsync(counts, t.n_before, (size_t)B * 4, hipMemcpyDeviceToDevice, st), name);
     return GS_OK;
 }
 // valid pixels of batch element b (n_arrays row arrays) appended behind the rows its arena already holds

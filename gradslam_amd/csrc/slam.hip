@@ -163,6 +163,15 @@ int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const
                             const int *h_row_floats, float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended,
                             int32_t *d_overflow, void *cws, hipStream_t st);
 
+size_t fusion_tape_bytes(int B, int H, int W);
+int fusion_tape_record(const void *state, void *tape, int B, int H, int W, int Nmax, const int32_t *counts, const float *points,
+                       const float *normals, const float *colors, const float *ccounts, hipStream_t st);
+int fusion_tape_appended(void *tape, int B, int H, int W, const int32_t *appended, hipStream_t st);
+int fusion_update_reverse(const void *tape, int B, int H, int W, int Nmax, const float *depth, const float *gvertex,
+                          const float *gnormal, const float *rgb, const float *alpha, float *points, float *normals, float *colors,
+                          float *ccounts, int32_t *counts, float *Gp, float *Gn, float *Gc, float *Gcc, float *g_gvertex,
+                          float *g_gnormal, float *g_rgb, float *g_alpha, void *cws, hipStream_t st);
+
 int append_valid_pixels(int n_arrays, const float *depth_b, int64_t HW, const float *const *h_src, const int *h_row_floats,
                         float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended, int32_t *d_overflow, void *cws,
                         hipStream_t st);
@@ -273,7 +282,7 @@ __global__ void scatter_grads_k(const float *__restrict__ g_src, const int32_t *
                                 int capS, int Wd, int ds, int H, int W, float *__restrict__ g_gvertex /* this b */,
                                 const float *__restrict__ g_tgt, const float *__restrict__ g_nrm,
                                 const int32_t *__restrict__ tgt_index, const int32_t *__restrict__ nt, int capT,
-                                float *__restrict__ g_map_points, float *__restrict__ g_map_normals /* this b */) {
+                                float *__restrict__ g_map_points, float *__restrict__ g_map_normals /* this b */, int accumulate) {
     const int n_s = min(*ns, capS), n_t = min(*nt, capT);
     const int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s; i += stride) {
@@ -283,8 +292,13 @@ __global__ void scatter_grads_k(const float *__restrict__ g_src, const int32_t *
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_t; k += stride) {
         const int64_t at = tgt_index[k];
-        if (g_map_points) st3(g_map_points, at, ld3(g_tgt, k));
-        if (g_map_normals) st3(g_map_normals, at, ld3(g_nrm, k));
+        f3 gp = g_map_points ? ld3(g_tgt, k) : f3{0, 0, 0}, gq = g_map_normals ? ld3(g_nrm, k) : f3{0, 0, 0};
+        if (accumulate) {  // a running adjoint of the whole map (one slot per map point: no atomics needed)
+            if (g_map_points) { const f3 o = ld3(g_map_points, at); gp = f3{o.x + gp.x, o.y + gp.y, o.z + gp.z}; }
+            if (g_map_normals) { const f3 o = ld3(g_map_normals, at); gq = f3{o.x + gq.x, o.y + gq.y, o.z + gq.z}; }
+        }
+        if (g_map_points) st3(g_map_points, at, gp);
+        if (g_map_normals) st3(g_map_normals, at, gq);
     }
 }
 
@@ -440,11 +454,10 @@ size_t gs_pointfusion_update_ws_bytes(int B, int H, int W, int Nmax) {
     return fuse_layout(B, H, W, Nmax, nullptr, nullptr);
 }
 
-int gs_pointfusion_update(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H, int W,
-                          float *map_points, float *map_normals, float *map_colors, float *map_ccounts, int32_t *map_counts,
-                          int Nmax, float dist_th, float dot_th, float sigma, int32_t *stats, void *ws, size_t ws_bytes,
-                          gs_stream_t stream) {
-    const char *name = "gs_pointfusion_update";
+static int pointfusion_update_impl(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H, int W,
+                                   float *map_points, float *map_normals, float *map_colors, float *map_ccounts, int32_t *map_counts,
+                                   int Nmax, float dist_th, float dot_th, float sigma, int32_t *stats, void *ws, size_t ws_bytes,
+                                   gs_stream_t stream, void *tape, const char *name) {
     GS_REQUIRE(depth && rgb && intrinsics && poses && map_points && map_normals && map_colors && map_ccounts && map_counts,
                "%s: NULL argument", name);
     GS_REQUIRE(B > 0 && B <= 60 && H >= 2 && W >= 2 && Nmax > 0, "%s: bad shape", name);
@@ -468,6 +481,9 @@ int gs_pointfusion_update(const float *depth, const float *rgb, const float *int
                                 w.max_dot, stream))) return rc;
     if ((rc = fusion_unique_match(w.rows, w.keep, w.nrows, npt, w.gV, B, H, W, map_points, map_ccounts, Nmax, w.urows, w.ucnt, w.state,
                                   w.sub, st))) return rc;
+    // differentiable form: the winners and the matched rows' values before the merge go to the tape
+    if (tape && (rc = fusion_tape_record(w.state, tape, B, H, W, Nmax, map_counts, map_points, map_normals, map_colors, map_ccounts, st)))
+        return rc;
     // fuse_with_map (fusionutils.py:654-720): merge in place, then append the unmatched valid pixels
     if ((rc = fusion_merge_prebuilt(w.state, w.ucnt, w.gV, w.gN, rgb, w.alpha, B, H, W, Nmax, map_counts, map_points, map_normals,
                                     map_colors, map_ccounts, st))) return rc;
@@ -480,12 +496,78 @@ int gs_pointfusion_update(const float *depth, const float *rgb, const float *int
         if ((rc = fusion_append_unmatched(w.state, B, H, W, b, depth, src, widths, dst, map_counts + b, Nmax, w.appended + b,
                                           w.overflow, w.sub, st))) return rc;
     }
+    if (tape && (rc = fusion_tape_appended(tape, B, H, W, w.appended, st))) return rc;
     if (stats) {
         hipLaunchKernelGGL(fuse_stats_k, dim3(1), dim3(64), 0, st, w.nrows, w.ucnt, w.overflow, w.max_dot, w.appended, B, stats);
         GS_LAUNCH_CHECK(name);
     }
     return GS_OK;
 }
+
+int gs_pointfusion_update(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H, int W,
+                          float *map_points, float *map_normals, float *map_colors, float *map_ccounts, int32_t *map_counts,
+                          int Nmax, float dist_th, float dot_th, float sigma, int32_t *stats, void *ws, size_t ws_bytes,
+                          gs_stream_t stream) {
+    return pointfusion_update_impl(depth, rgb, intrinsics, poses, B, H, W, map_points, map_normals, map_colors, map_ccounts, map_counts,
+                                   Nmax, dist_th, dot_th, sigma, stats, ws, ws_bytes, stream, nullptr, "gs_pointfusion_update");
+}
+
+size_t gs_pointfusion_update_tape_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return fusion_tape_bytes(B, H, W);
+}
+
+int gs_pointfusion_update_taped(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H, int W,
+                                float *map_points, float *map_normals, float *map_colors, float *map_ccounts, int32_t *map_counts,
+                                int Nmax, float dist_th, float dot_th, float sigma, int32_t *stats, void *tape, size_t tape_bytes,
+                                void *ws, size_t ws_bytes, gs_stream_t stream) {
+    GS_REQUIRE(tape && tape_bytes >= gs_pointfusion_update_tape_bytes(B, H, W), "gs_pointfusion_update_taped: tape missing or too small");
+    return pointfusion_update_impl(depth, rgb, intrinsics, poses, B, H, W, map_points, map_normals, map_colors, map_ccounts, map_counts,
+                                   Nmax, dist_th, dot_th, sigma, stats, ws, ws_bytes, stream, tape, "gs_pointfusion_update_taped");
+}
+
+size_t gs_pointfusion_update_backward_ws_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t npix = (size_t)B * H * W;
+    // V, N, gV, gN (recomputed), alpha, g_alpha + the compaction's scratch
+    return 4 * align_up(npix * 12, 256) + 2 * align_up(npix * 4, 256) + gs_compact_ws_bytes((int64_t)H * W) + 512;
+}
+
+int gs_pointfusion_update_backward(const float *depth, const float *rgb, const float *intrinsics, const float *poses, int B, int H,
+                                   int W, float *map_points, float *map_normals, float *map_colors, float *map_ccounts,
+                                   int32_t *map_counts, int Nmax, float sigma, const void *tape, size_t tape_bytes, float *G_points,
+                                   float *G_normals, float *G_colors, float *G_ccounts, float *g_vertex, float *g_gvertex,
+                                   float *g_gnormal, float *g_rgb, void *ws, size_t ws_bytes, gs_stream_t stream) {
+    const char *name = "gs_pointfusion_update_backward";
+    GS_REQUIRE(depth && rgb && intrinsics && poses && map_points && map_normals && map_colors && map_ccounts && map_counts && tape &&
+                   G_points && G_normals && G_colors && G_ccounts && g_vertex && g_gvertex && g_gnormal && g_rgb, "%s: NULL argument", name);
+    GS_REQUIRE(B > 0 && B <= 60 && H >= 2 && W >= 2 && Nmax > 0, "%s: bad shape", name);
+    GS_REQUIRE(tape_bytes >= gs_pointfusion_update_tape_bytes(B, H, W), "%s: tape too small", name);
+    if (!ws || ws_bytes < gs_pointfusion_update_backward_ws_bytes(B, H, W)) {
+        set_error("%s: workspace too small (%zu < %zu)", name, ws_bytes, gs_pointfusion_update_backward_ws_bytes(B, H, W));
+        return GS_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    char *p = (char *)ws;
+    auto take = [&](size_t bytes) { char *o = p; p += align_up(bytes, 256); return o; };
+    float *V = (float *)take(npix * 12), *N = (float *)take(npix * 12), *gV = (float *)take(npix * 12), *gN = (float *)take(npix * 12);
+    float *alpha = (float *)take(npix * 4), *g_alpha = (float *)take(npix * 4);
+    void *cws = p;
+    int rc;
+    // the frame's maps and sample confidences again (cheaper to recompute than to keep per frame)
+    if ((rc = gs_vertex_normal_maps(depth, intrinsics, poses, B, 1, H, W, V, N, gV, gN, stream))) return rc;
+    if ((rc = gs_get_alpha(V, (int64_t)npix, sigma, 1e-7f, alpha, stream))) return rc;
+    if ((rc = fusion_update_reverse(tape, B, H, W, Nmax, depth, gV, gN, rgb, alpha, map_points, map_normals, map_colors, map_ccounts,
+                                    map_counts, G_points, G_normals, G_colors, G_ccounts, g_gvertex, g_gnormal, g_rgb, g_alpha, cws, st)))
+        return rc;
+    // alpha = f(local vertex map): its adjoint is the only one the local vertex map receives from the update
+    // (gs_get_alpha_backward adds into its output)
+    GS_HIP(hipMemsetAsync(g_vertex, 0, npix * 12, st), name);
+    return gs_get_alpha_backward(V, (int64_t)npix, sigma, 1e-7f, g_alpha, g_vertex, stream);
+}
+
+
 
 size_t gs_aggregate_update_ws_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -591,7 +673,7 @@ int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int 
                               const float *map_normals, int Nmax, int use_grad_lm, int numiters, float dist_thresh,
                               float lambda_max, float Bp, float B2, float nu, const void *tape, size_t tape_bytes,
                               const float *grad_out_poses, float *grad_gvertex, float *grad_map_points, float *grad_map_normals,
-                              float *grad_prev_poses, void *ws, size_t ws_bytes, gs_stream_t stream) {
+                              float *grad_prev_poses, int accumulate_map_grads, void *ws, size_t ws_bytes, gs_stream_t stream) {
     const char *name = "gs_slam_localize_backward";
     GS_REQUIRE(prev_poses && map_points && map_normals && tape && grad_out_poses && grad_gvertex && grad_prev_poses,
                "%s: NULL argument", name);
@@ -615,8 +697,8 @@ int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int 
     const size_t sub_bytes = gs_icp_backward_ws_bytes(capS);
 
     GS_HIP(hipMemsetAsync(grad_gvertex, 0, (size_t)B * H * W * 12, st), name);
-    if (grad_map_points) GS_HIP(hipMemsetAsync(grad_map_points, 0, (size_t)B * Nmax * 12, st), name);
-    if (grad_map_normals) GS_HIP(hipMemsetAsync(grad_map_normals, 0, (size_t)B * Nmax * 12, st), name);
+    if (grad_map_points && !accumulate_map_grads) GS_HIP(hipMemsetAsync(grad_map_points, 0, (size_t)B * Nmax * 12, st), name);
+    if (grad_map_normals && !accumulate_map_grads) GS_HIP(hipMemsetAsync(grad_map_normals, 0, (size_t)B * Nmax * 12, st), name);
     hipLaunchKernelGGL(eye4_k, dim3(cdiv(16 * B, 64)), dim3(64), 0, st, eye, B);
     hipLaunchKernelGGL(compose_bwd_k, dim3(cdiv(B, 64)), dim3(64), 0, st, tp.T, prev_poses, grad_out_poses, B, g_T, grad_prev_poses);
     GS_LAUNCH_CHECK(name);
@@ -635,7 +717,7 @@ int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int 
         hipLaunchKernelGGL(scatter_grads_k, dim3(gb), dim3(256), 0, st, g_src, tp.src_pix + (size_t)b * capS, tp.ns + b, capS,
                            cdiv(W, ds), ds, H, W, grad_gvertex + (size_t)b * H * W * 3, g_tgt, g_nrm, tp.tgt_index + (size_t)b * capT,
                            tp.nt + b, capT, grad_map_points ? grad_map_points + (size_t)b * Nmax * 3 : nullptr,
-                           grad_map_normals ? grad_map_normals + (size_t)b * Nmax * 3 : nullptr);
+                           grad_map_normals ? grad_map_normals + (size_t)b * Nmax * 3 : nullptr, accumulate_map_grads);
         GS_LAUNCH_CHECK(name);
     }
     return GS_OK;

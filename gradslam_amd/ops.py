@@ -58,18 +58,24 @@ class _MapsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gV_l, gN_l, gV_g, gN_g):
         depth, K, poses = ctx.saved_tensors
-        depth_c, K_c, poses_c = _f32c(depth), _f32c(K), _f32c(poses)
-        B, L, H, W = depth.shape[:4]
-        fix = lambda g: None if (g is None or g.numel() == 0) else _f32c(g)
-        gV_l, gN_l, gV_g, gN_g = fix(gV_l), fix(gN_l), fix(gV_g), fix(gN_g)
-        g_depth = torch.zeros_like(depth_c)
-        g_K = torch.zeros_like(K_c)
-        g_P = torch.zeros_like(poses_c) if poses_c is not None else None
-        nb = ws_bytes("gs_vertex_normal_maps_backward_ws_bytes", B, L, H, W)
-        ws = workspace(nb, depth.device, "maps_bwd")
-        call("gs_vertex_normal_maps_backward", ptr(depth_c), ptr(K_c), ptr(poses_c), B, L, H, W, ptr(gV_l), ptr(gN_l),
-             ptr(gV_g), ptr(gN_g), ptr(g_depth), ptr(g_K), ptr(g_P), ptr(ws), ws.numel(), stream())
+        fix = lambda g: None if (g is None or g.numel() == 0) else g
+        g_depth, g_K, g_P = vertex_normal_maps_backward_raw(depth, K, poses, fix(gV_l), fix(gN_l), fix(gV_g), fix(gN_g))
         return g_depth.view_as(depth), g_K.view_as(K), (g_P.view_as(poses) if g_P is not None else None), None, None
+
+
+def vertex_normal_maps_backward_raw(depth, K, poses, gV_l=None, gN_l=None, gV_g=None, gN_g=None):
+    """Adjoint of vertex_normal_maps_raw: given the adjoints of any of the four maps (None = zero) returns
+    (g_depth, g_K, g_poses or None), freshly allocated and fully written."""
+    depth_c, K_c, poses_c = _f32c(depth), _f32c(K), _f32c(poses)
+    B, L, H, W = depth_c.shape[:4]
+    gV_l, gN_l, gV_g, gN_g = _f32c(gV_l), _f32c(gN_l), _f32c(gV_g), _f32c(gN_g)
+    g_depth = torch.zeros_like(depth_c)
+    g_K = torch.zeros_like(K_c)
+    g_P = torch.zeros_like(poses_c) if poses_c is not None else None
+    ws = workspace(ws_bytes("gs_vertex_normal_maps_backward_ws_bytes", B, L, H, W), depth_c.device, "maps_bwd")
+    call("gs_vertex_normal_maps_backward", ptr(depth_c), ptr(K_c), ptr(poses_c), B, L, H, W, ptr(gV_l), ptr(gN_l),
+         ptr(gV_g), ptr(gN_g), ptr(g_depth), ptr(g_K), ptr(g_P), ptr(ws), ws.numel(), stream())
+    return g_depth, g_K, g_P
 
 
 def vertex_normal_maps(depth, K, poses, want_local=True, want_global=True):
@@ -549,7 +555,7 @@ class _LocalizeFn(torch.autograd.Function):
         g_prev = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
         ws = workspace(ws_bytes("gs_slam_localize_backward_ws_bytes", B, H, W, ds, Nmax), dev, "localize_bwd")
         call("gs_slam_localize_backward", ptr(prev), B, H, W, ds, ptr(mp), ptr(mn), Nmax, grad_lm, numiters, thresh, lmax, Bp, B2,
-             nu, ptr(tape), tape.numel(), ptr(g_out), ptr(g_gV), ptr(g_mp), ptr(g_mn), ptr(g_prev), ptr(ws), ws.numel(), stream())
+             nu, ptr(tape), tape.numel(), ptr(g_out), ptr(g_gV), ptr(g_mp), ptr(g_mn), ptr(g_prev), 0, ptr(ws), ws.numel(), stream())
         return g_gV, None, None, g_prev, g_mp, g_mn, None, None, None, None, None, None
 
 
@@ -593,6 +599,135 @@ def aggregate_update_raw(depth, rgb, K, poses, map_points, map_normals, map_colo
     ws = workspace(ws_bytes("gs_aggregate_update_ws_bytes", B, H, W), depth.device, "aggregate_step")
     call("gs_aggregate_update", ptr(depth), ptr(rgb), ptr(K), ptr(poses), B, H, W, ptr(map_points), ptr(map_normals),
          ptr(map_colors), ptr(map_counts_i32), map_points.shape[1], ptr(stats), ptr(ws), ws.numel(), stream())
+
+
+class _PointFusionSeqFn(torch.autograd.Function):
+    """PointFusion over a whole sequence as ONE autograd node (one sequence: B = 1).
+
+    forward  = the arena-backed frame loop with the taped forms of its two calls per frame
+               (gs_slam_localize_taped, gs_pointfusion_update_taped): no host synchronisation until the map is
+               handed back, the map updated in place.
+    backward = the frames in reverse on a copy of the final arena: per frame gs_pointfusion_update_backward (pulls the
+               running adjoint of the whole map back through merge + append at the matched / appended rows only and
+               restores the arena to the previous frame's), the adjoint of the frame's vertex / normal maps, then
+               gs_slam_localize_backward (adds the ICP targets' adjoints into the running map adjoint) and the adjoint of
+               the live maps under the previous pose.  What is a constant in the reference's graph is a constant here
+               (correspondence tables, association indices, accept decisions).
+    reference: torch autograd through slam/icpslam.py:125-137 with slam/pointfusion.py:107-112."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, K, poses, cfg):
+        odom, ds, numiters, damp, dist_thresh, gparams, dist_th, dot_th, sigma, arena_cls = cfg
+        rgb, depth, K = _f32c(rgb.detach()), _f32c(depth.detach()), _f32c(K.detach())
+        poses_c = _f32c(poses.detach()) if poses is not None else None
+        B, L, H, W = depth.shape[:4]
+        dev = depth.device
+        arena = arena_cls(B, H * W, dev, with_features=True)
+        recovered = torch.empty((B, L, 4, 4), dtype=torch.float32, device=dev)
+        stats = torch.zeros((L, 4 + B), dtype=torch.int32, device=dev)
+        grad_lm = 1 if gparams is not None else 0
+        lmax, Bp, B2, nu = gparams if gparams is not None else (2.0, 1.0, 1.0, 200.0)
+        fuse_tape_b = ws_bytes("gs_pointfusion_update_tape_bytes", B, H, W)
+        frames = []
+        prev, bound = None, None
+        for s in range(L):
+            d_s, c_s = depth[:, s].contiguous(), rgb[:, s].contiguous()
+            rec = {}
+            if s == 0 or odom == "gt":
+                pose = (poses_c[:, s:s + 1].contiguous() if poses_c is not None else
+                        torch.eye(4, dtype=torch.float32, device=dev).view(1, 1, 4, 4).repeat(B, 1, 1, 1))
+            else:
+                mp, mn, _, _ = arena.rows(bound)
+                _, _, gV, _ = vertex_normal_maps_raw(d_s.unsqueeze(1), K, prev, want_local=False, want_global=True)
+                pose = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+                tape = torch.empty(ws_bytes("gs_slam_localize_tape_bytes", B, H, W, int(ds), bound, int(numiters), grad_lm),
+                                   dtype=torch.uint8, device=dev)
+                ws = workspace(ws_bytes("gs_slam_localize_ws_bytes", B, H, W, int(ds), bound), dev, "localize")
+                call("gs_slam_localize_taped", ptr(d_s), ptr(gV), ptr(K), ptr(prev), B, H, W, int(ds), ptr(mp), ptr(mn),
+                     ptr(arena.counts), bound, grad_lm, int(numiters), float(damp), _thresh(dist_thresh), float(lmax), float(Bp),
+                     float(B2), float(nu), ptr(pose), ptr(tape), tape.numel(), ptr(ws), ws.numel(), stream())
+                rec["loc"] = (tape, bound)
+            bound = arena.reserve_frame()
+            mp, mn, mc, mf = arena.rows(bound)
+            ftape = torch.empty(fuse_tape_b, dtype=torch.uint8, device=dev)
+            ws = workspace(ws_bytes("gs_pointfusion_update_ws_bytes", B, H, W, bound), dev, "fusion_step")
+            call("gs_pointfusion_update_taped", ptr(d_s), ptr(c_s), ptr(K), ptr(pose), B, H, W, ptr(mp), ptr(mn), ptr(mc), ptr(mf),
+                 ptr(arena.counts), bound, float(dist_th), float(dot_th), float(sigma), ptr(stats[s]), ptr(ftape), ftape.numel(),
+                 ptr(ws), ws.numel(), stream())
+            arena.appended()
+            rec["fuse"] = (ftape, bound)
+            frames.append(rec)
+            recovered[:, s] = pose[:, 0]
+            prev = pose
+        n = arena.counts.tolist()  # the one host synchronisation of the sequence
+        ctx.arena, ctx.frames, ctx.n_final = arena, frames, n
+        ctx.cfg = (odom, int(ds), int(numiters), _thresh(dist_thresh), grad_lm, float(lmax), float(Bp), float(B2), float(nu), float(sigma))
+        ctx.has_poses = poses is not None
+        ctx.save_for_backward(rgb, depth, K, recovered)
+        ctx.stats = stats
+        cut = lambda x: x[:, : n[0]].clone()
+        return cut(arena.points), cut(arena.normals), cut(arena.colors), cut(arena.ccounts), recovered.clone(), stats
+
+    @staticmethod
+    def backward(ctx, g_p, g_n, g_c, g_f, g_poses, _g_stats):
+        rgb, depth, K, recovered = ctx.saved_tensors
+        odom, ds, numiters, thresh, grad_lm, lmax, Bp, B2, nu, sigma = ctx.cfg
+        arena, frames, n_final = ctx.arena, ctx.frames, ctx.n_final[0]
+        B, L, H, W = depth.shape[:4]
+        dev = depth.device
+        cap = arena.cap
+        # work on copies: the arena is restored frame by frame, the running adjoint of the map is pulled back in place
+        mp, mn, mc, mf = (x.clone() for x in (arena.points, arena.normals, arena.colors, arena.ccounts))
+        counts = arena.counts.clone()
+
+        def running(g, c):
+            G = torch.zeros((B, cap, c), dtype=torch.float32, device=dev)
+            if g is not None:
+                G[:, :n_final] = g
+            return G
+
+        Gp, Gn, Gc, Gf = running(g_p, 3), running(g_n, 3), running(g_c, 3), running(g_f, 1)
+        gpose = g_poses.clone().float() if g_poses is not None else torch.zeros((B, L, 4, 4), dtype=torch.float32, device=dev)
+        g_rgb, g_depth, g_K = torch.zeros_like(rgb), torch.zeros_like(depth), torch.zeros_like(K)
+        g_poses_in = torch.zeros((B, L, 4, 4), dtype=torch.float32, device=dev) if ctx.has_poses else None
+        mk = lambda c: torch.empty((B, H, W, c), dtype=torch.float32, device=dev)
+        g_V, g_gV, g_gN, g_c_s = mk(3), mk(3), mk(3), mk(3)
+        for s in reversed(range(L)):
+            d_s, c_s = depth[:, s].contiguous(), rgb[:, s].contiguous()
+            pose_s = recovered[:, s:s + 1].contiguous()
+            ftape, bound = frames[s]["fuse"]
+            ws = workspace(ws_bytes("gs_pointfusion_update_backward_ws_bytes", B, H, W), dev, "fusion_bwd")
+            call("gs_pointfusion_update_backward", ptr(d_s), ptr(c_s), ptr(K), ptr(pose_s), B, H, W, ptr(mp), ptr(mn), ptr(mc), ptr(mf),
+                 ptr(counts), bound, sigma, ptr(ftape), ftape.numel(), ptr(Gp), ptr(Gn), ptr(Gc), ptr(Gf), ptr(g_V), ptr(g_gV),
+                 ptr(g_gN), ptr(g_c_s), ptr(ws), ws.numel(), stream())
+            g_rgb[:, s] = g_c_s.view_as(g_rgb[:, s])
+            gd, gk, gP = vertex_normal_maps_backward_raw(d_s.unsqueeze(1), K, pose_s, g_V.unsqueeze(1), None, g_gV.unsqueeze(1),
+                                                         g_gN.unsqueeze(1))
+            g_depth[:, s] += gd.view_as(g_depth[:, s])
+            g_K += gk.view_as(g_K)
+            gpose[:, s] += gP.view(B, 4, 4)
+            if "loc" in frames[s]:
+                tape, nmax = frames[s]["loc"]
+                prev = recovered[:, s - 1:s].contiguous()
+                g_live = torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev)
+                g_prev = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+                ws = workspace(ws_bytes("gs_slam_localize_backward_ws_bytes", B, H, W, ds, nmax), dev, "localize_bwd")
+                call("gs_slam_localize_backward", ptr(prev), B, H, W, ds, ptr(mp), ptr(mn), nmax, grad_lm, numiters, thresh, lmax, Bp, B2,
+                     nu, ptr(tape), tape.numel(), ptr(gpose[:, s:s + 1].contiguous()), ptr(g_live), ptr(Gp), ptr(Gn), ptr(g_prev), 1,
+                     ptr(ws), ws.numel(), stream())
+                gd, gk, gP = vertex_normal_maps_backward_raw(d_s.unsqueeze(1), K, prev, None, None, g_live, None)
+                g_depth[:, s] += gd.view_as(g_depth[:, s])
+                g_K += gk.view_as(g_K)
+                gpose[:, s - 1] += gP.view(B, 4, 4) + g_prev.view(B, 4, 4)
+            elif g_poses_in is not None:
+                g_poses_in[:, s] += gpose[:, s]
+        return g_rgb, g_depth, g_K, g_poses_in, None
+
+
+def pointfusion_sequence_autograd(rgb, depth, K, poses, cfg):
+    """-> (points, normals, colors, ccounts (1, N, C) each, recovered poses (1, L, 4, 4), stats) with grad_fn."""
+    require_hip(rgb, depth, K, poses, op="pointfusion_sequence")
+    return _PointFusionSeqFn.apply(rgb, depth, K, poses, cfg)
 
 
 # ---------------------------------------------------------------------------------------------- C / U / F / A

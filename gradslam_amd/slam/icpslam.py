@@ -139,6 +139,12 @@ class ICPSLAM(nn.Module):
     # results as the step-by-step path (same kernels); `streamed = False` forces the latter.
     streamed = True
     fused_map = True   # step(): the mapping step as one fused call when nothing needs gradients (False = staged)
+    # forward() WITH gradients as one autograd node per sequence (PointFusion, one sequence per call); False = one node
+    # per op / per localisation, kept as the independent check of the fused reverse pass
+    fused_sequence_autograd = True
+
+    def _can_fuse_sequence(self, frames) -> bool:
+        return False  # ICPSLAM's aggregate map keeps the per-frame nodes (PointFusion overrides)
     _arena_features = False
 
     def forward(self, frames: RGBDImages):
@@ -147,6 +153,8 @@ class ICPSLAM(nn.Module):
             raise TypeError("Expected frames to be of type gradslam.RGBDImages. Got {0}.".format(type(frames)))
         if self.streamed and self._can_stream(frames):
             return self._forward_streamed(frames)
+        if self.fused_sequence_autograd and self._can_fuse_sequence(frames):
+            return self._forward_sequence_node(frames)
         pointclouds = Pointclouds(device=self.device)
         batch_size, seq_len = frames.shape[:2]
         recovered_poses = torch.empty(batch_size, seq_len, 4, 4).to(self.device)

@@ -53,6 +53,36 @@ class PointFusion(ICPSLAM):
         ops.pointfusion_update_raw(depth_s, rgb_s, K, pose, mp, mn, mc, mf, arena.counts, self.dist_th, self.dot_th, self.sigma,
                                    stats_row)
 
+    def _can_fuse_sequence(self, frames) -> bool:
+        """forward() with gradients as one node: one channels-last float32 sequence on the device, the mapping step not
+        overridden by a subclass."""
+        if not getattr(type(self)._map, "_gs_arena_form", False) or frames.channels_first or self.device.type != "cuda":
+            return False
+        tensors = (frames.rgb_image, frames.depth_image, frames.intrinsics, frames.poses)
+        if frames.poses is None and self.odom == "gt":
+            return False
+        if any(t is not None and (not t.is_cuda or t.dtype != torch.float32) for t in tensors):
+            return False
+        if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)):
+            return False  # nothing to differentiate: the streamed / step-by-step drivers
+        return frames.shape[0] == 1 and frames.shape[2] >= 2 and frames.shape[3] >= 2
+
+    def _forward_sequence_node(self, frames: RGBDImages):
+        from .. import ops
+        from .icpslam import _MapArena
+
+        p = self.odomprov
+        gparams = (p.lambda_max, p.B, p.B2, p.nu) if self.odom == "gradicp" else None
+        cfg = (self.odom, self.dsratio, p.numiters if p is not None else 0, p.damp if p is not None else 0.0,
+               p.dist_thresh if p is not None else None, gparams, self.dist_th, self.dot_th, self.sigma, _MapArena)
+        pts, nrm, col, cc, poses, stats = ops.pointfusion_sequence_autograd(frames.rgb_image, frames.depth_image, frames.intrinsics,
+                                                                            frames.poses, cfg)
+        for s, row in enumerate(stats.tolist()):  # the reference's warnings, raised once the sequence is done
+            if row[2]:
+                raise RuntimeError("map arena overflow at frame {} (internal capacity bound violated)".format(s))
+            self._stream_warnings(s, row)
+        return Pointclouds(points=[pts[0]], normals=[nrm[0]], colors=[col[0]], features=[cc[0]]), poses
+
     def _stream_warnings(self, s, row):
         if s == 0:
             return

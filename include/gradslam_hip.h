@@ -296,6 +296,32 @@ int gs_pointfusion_update(const float *depth, const float *rgb, const float *int
                           float *map_ccounts, int32_t *map_counts, int Nmax, float dist_th, float dot_th,
                           float sigma, int32_t *stats, void *ws, size_t ws_bytes, gs_stream_t stream);
 
+/* update_map_fusion with gradients, as ONE node per sequence (reference: torch autograd through
+ * slam/fusionutils.py:654-720 and structures/pointclouds.py:1203-1235, frame after frame).
+ * Forward = gs_pointfusion_update (same arguments, same in-place result) that also fills `tape`
+ * (gs_pointfusion_update_tape_bytes): per pixel the map point it merged into, the ten attribute floats that point held
+ * before the merge, and the row counts before the append.
+ * Backward (frames in reverse order; G_* = running adjoint of the WHOLE map, (B,Nmax,C) like the map arrays, holding
+ * the adjoint of the map AFTER this frame on entry and of the map BEFORE it on return): pulls G back through the merge
+ * at the matched rows only (an unmatched point passes its adjoint through: x' = (c x + 0)/c), reads the appended rows'
+ * adjoints out behind the previous count, writes the frame's adjoints g_vertex (local vertex map, through alpha),
+ * g_gvertex, g_gnormal, g_rgb (B,H,W,3 each, fully written) and RESTORES map_* / map_counts to the previous frame's,
+ * so that the localisation's reverse pass of the same frame finds the map it ran against.  O(pixels) per frame,
+ * no host synchronisation. */
+size_t gs_pointfusion_update_tape_bytes(int B, int H, int W);
+int gs_pointfusion_update_taped(const float *depth, const float *rgb, const float *intrinsics, const float *poses,
+                                int B, int H, int W, float *map_points, float *map_normals, float *map_colors,
+                                float *map_ccounts, int32_t *map_counts, int Nmax, float dist_th, float dot_th,
+                                float sigma, int32_t *stats, void *tape, size_t tape_bytes, void *ws,
+                                size_t ws_bytes, gs_stream_t stream);
+size_t gs_pointfusion_update_backward_ws_bytes(int B, int H, int W);
+int gs_pointfusion_update_backward(const float *depth, const float *rgb, const float *intrinsics, const float *poses,
+                                   int B, int H, int W, float *map_points, float *map_normals, float *map_colors,
+                                   float *map_ccounts, int32_t *map_counts, int Nmax, float sigma, const void *tape,
+                                   size_t tape_bytes, float *G_points, float *G_normals, float *G_colors,
+                                   float *G_ccounts, float *g_vertex, float *g_gvertex, float *g_gnormal,
+                                   float *g_rgb, void *ws, size_t ws_bytes, gs_stream_t stream);
+
 /* The same for ICPSLAM's aggregate map (update_map_aggregate, slam/fusionutils.py:725-758 with inplace=True): the
  * global vertices, normals and colours of every valid live-frame pixel are appended, unmerged, in (h, w) order
  * behind the rows the arena holds; map_counts advances on the device.  stats (optional, 4 + B int32): [2] = overflow
@@ -327,7 +353,9 @@ int gs_slam_localize_backward(const float *prev_poses, int B, int H, int W, int 
                               float dist_thresh, float lambda_max, float Bp, float B2, float nu,
                               const void *tape, size_t tape_bytes, const float *grad_out_poses,
                               float *grad_gvertex, float *grad_map_points, float *grad_map_normals,
-                              float *grad_prev_poses, void *ws, size_t ws_bytes, gs_stream_t stream);
+                              float *grad_prev_poses, int accumulate_map_grads /* 1: add into grad_map_* (a running
+                              adjoint of the whole map) instead of overwriting them */,
+                              void *ws, size_t ws_bytes, gs_stream_t stream);
 
 /* gs_slam_localize can replay its ICP loops as a cached hipGraph once a configuration repeats (all loop
  * arguments live in the caller's workspace).  mode: 1 on, 0 off (eager launches), -1 automatic: the library
