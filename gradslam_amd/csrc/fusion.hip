@@ -282,10 +282,14 @@ __global__ void fuse_bwd_matched_k(const unsigned int *__restrict__ t_pix_n, con
                                    const float *__restrict__ alpha, float *__restrict__ p, float *__restrict__ nn,
                                    float *__restrict__ cl, float *__restrict__ cc, float *__restrict__ Gp, float *__restrict__ Gn,
                                    float *__restrict__ Gc, float *__restrict__ Gcc, float *__restrict__ ggv, float *__restrict__ ggn,
-                                   float *__restrict__ grgb, float *__restrict__ galpha) {
+                                   float *__restrict__ grgb, float *__restrict__ galpha, const float *__restrict__ depth) {
     for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
         const unsigned int n = t_pix_n[pix];
-        if (n == 0xffffffffu) continue;
+        if (n == 0xffffffffu) {
+            // appended pixels (valid depth, no match) were written by the append's reverse; the rest receive nothing
+            if (!(depth[pix] > 0.0f)) { st3(ggv, pix, f3{0, 0, 0}); st3(ggn, pix, f3{0, 0, 0}); st3(grgb, pix, f3{0, 0, 0}); galpha[pix] = 0.0f; }
+            continue;
+        }
         const int64_t pt = (pix / HW) * (int64_t)Nmax + n;
         const float *o = t_old + 10 * pix;
         const f3 x{o[0], o[1], o[2]}, y{o[3], o[4], o[5]}, z{o[6], o[7], o[8]};
@@ -546,10 +550,7 @@ int fusion_update_reverse(const void *tape, int B, int H, int W, int Nmax, const
     const char *name = "gs_pointfusion_update_backward";
     const FusionTape t = fusion_tape_ptrs((void *)tape, B, H, W);
     const int64_t npix = (int64_t)B * H * W, HW = (int64_t)H * W;
-    GS_HIP(hipMemsetAsync(g_gvertex, 0, npix * 12, st), name);
-    GS_HIP(hipMemsetAsync(g_gnormal, 0, npix * 12, st), name);
-    GS_HIP(hipMemsetAsync(g_rgb, 0, npix * 12, st), name);
-    GS_HIP(hipMemsetAsync(g_alpha, 0, npix * 4, st), name);
+    // every pixel is written exactly once: appended ones here, matched and invalid ones by fuse_bwd_matched_k
     for (int b = 0; b < B; ++b) {  // appended pixels: their rows sit behind n_before[b]
         AppendBwdWriter wr;
         const float *G[4] = {Gp + (size_t)b * Nmax * 3, Gn + (size_t)b * Nmax * 3, Gc + (size_t)b * Nmax * 3, Gcc + (size_t)b * Nmax};
@@ -564,7 +565,7 @@ int fusion_update_reverse(const void *tape, int B, int H, int W, int Nmax, const
     }
     hipLaunchKernelGGL(fuse_bwd_matched_k, dim3(grid1d(npix)), dim3(256), 0, st, (const unsigned int *)t.pix_n, (const float *)t.old, npix,
                        H * W, Nmax, gvertex, gnormal, rgb, alpha, points, normals, colors, ccounts, Gp, Gn, Gc, Gcc, g_gvertex, g_gnormal,
-                       g_rgb, g_alpha);
+                       g_rgb, g_alpha, depth);
     GS_LAUNCH_CHECK(name);
     GS_HIP(hipMemcpyAsync(counts, t.n_before, (size_t)B * 4, hipMemcpyDeviceToDevice, st), name);
     return GS_OK;

@@ -2,27 +2,35 @@
 // exponential / LM control (X), and whole ICP / gradICP loops that never leave the device.
 //
 // K  The reference's association is an exact K=1 nearest-neighbour search (squared L2 accumulated
-//    x->y->z in fp32 without FMA, strict '<' so the lowest index wins ties).  Two kernels compute it:
-//    * knn1_brute_k: every (source, target) pair.  FP32-VALU bound (8 flop/pair, no dense contraction
-//      -> no MFMA; a |p|^2+|q|^2-2p.q matrix form would change rounding and tie-breaks).  Target points
-//      are read with wave-uniform addresses, so they stream through the scalar cache into SGPRs.
-//    * knn1_box_k / knn1_loop_k (the ones the ICP loops use): the same pairs, minus those that provably
-//      cannot win.  Target points are grouped in chunks of 64 consecutive points (image order =>
-//      spatially compact) with an AABB each.  A wave owns 64 source points, seeds each lane's best with
-//      one real candidate (the previous iteration's neighbour, or the point at the same relative index),
-//      and skips a chunk iff every lane's fp32 lower bound ((ex^2+ey^2)+ez^2, e = per-axis distance to
-//      the box) is STRICTLY greater than that lane's current best.  Rounding is monotone and the bound
-//      uses the same operation order as the distance, so bound <= distance holds exactly in fp32: no
-//      epsilon, and the result is bit-identical to the brute-force scan (lexicographic (distance, index)
-//      minimum).
-//    Both split the target range over blockIdx.y to fill 256 CUs with ~19 k source points and merge
-//    with one 64-bit atomic min per (point, range) on the packed key  dist_bits<<32 | index.
+//    x->y->z in fp32 without FMA, strict '<' so the lowest index wins ties).  Three kernels compute it:
+//    * knn1_brute_k (the verifier): every (source, target) pair.  FP32-VALU bound (8 flop/pair, no dense contraction
+//      -> no MFMA; a |p|^2+|q|^2-2p.q matrix form would change rounding and tie-breaks).  Target points are read
+//      with wave-uniform addresses, so they stream through the scalar cache into SGPRs; the launch is split over
+//      (source tiles) x (target ranges) and merged with one 64-bit atomic min on the packed key dist_bits<<32 | index.
+//    * knn1_box_k / knn1_loop_k<false> (chunk-box search): the same pairs, minus those that provably cannot win.
+//      Target points are grouped in chunks of CHUNK = 16 consecutive points with an AABB each.  One 1024-thread
+//      block serves one tile of 64 source points: every wave holds the same 64 points (lane = point) and the 16 waves
+//      share the target chunks -- a coarse pass (lanes = chunk boxes, against the tile's box and loosest bound), then
+//      per-lane bounds ((ex^2+ey^2)+ez^2, e = per-axis gap to the box) and scans with candidates broadcast by
+//      v_readlane.  Rounding is monotone and the bound uses the distance's own operation order, so bound <= distance
+//      holds exactly in fp32: no epsilon, a chunk is skipped only on a STRICT '>', and the result is bit-identical to
+//      the brute-force scan (lexicographic (distance, index) minimum).
+//    * knn1_loop_k<true> (grid search with distance certificates, dense targets with search hints): every point
+//      examines the targets of the 3x3 ds-grid pixels around its window centre (staged in LDS) and a bound carried
+//      from association to association of one loop proves the window's best is the nearest neighbour; points whose
+//      proof fails take the chunk-box search again (see the comment above knn1_loop_k).
 // J  gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; wave
-//    butterflies + a fixed-order two-level tree (deterministic, no float atomics).
+//    butterflies + a fixed-order two-level tree (deterministic, no float atomics).  Fused into the association
+//    kernel's epilogue inside the loops; linearize_k / finalize44_k serve the stand-alone entry points.
 // X  the O(1) step of an iteration (reduce the partials, LM / gradLM decision, fp64 6x6 solve, SE(3)
-//    exponential) runs in the prologue of the NEXT association launch, recomputed by every block, published by
-//    block 0; only a loop's last step is a launch of its own.  Buffers are addressed through device-side role
-//    indices, so accept/reject needs no host round trip and no copies.
+//    exponential) runs in the prologue of the NEXT association launch: every block recomputes it on its wave 0
+//    (no block barriers inside; the other waves stage the grid search meanwhile), block 0 publishes it; only a loop's
+//    last step is a launch of its own.  Buffers are addressed through device-side role indices, so accept/reject
+//    needs no host round trip and no copies.  What is constant over a loop (pointers, hints, parameters) is read from
+//    a LoopConst in the workspace, not from kernel arguments: the SGPR count decides whether two blocks share a CU.
+// Gradients (X-bar): the taped loops + a device-side reverse pass.  The reverse pass scatters the adjoints of the
+//    associated target points / normals with float atomics (-munsafe-fp-atomics): forward results are bit-stable run
+//    to run, those two gradient arrays are not (sums of a few terms per target in arrival order, ~1e-7 relative).
 #include <stddef.h>
 #include <stdlib.h>
 #include <vector>

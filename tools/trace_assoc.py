@@ -17,3 +17,6 @@ print("last loop:", " ".join("%.1f" % x for x in m[-1]))
 print("first loop:", " ".join("%.1f" % x for x in m[0]))
 g = gap[:n - 1]
 print("gap to the next association launch us: p50 %.2f mean %.2f" % (np.percentile(g[g < 50], 50), g[g < 50].mean()))
+tot = m.sum(1)
+nb = 10
+print("per-loop association time (us), mean over consecutive tenths of the run:", " ".join("%.0f" % tot[i * len(tot) // nb:(i + 1) * len(tot) // nb].mean() for i in range(nb)))
