@@ -68,7 +68,11 @@ class _MapArena:
         self._tighten()
         need = self.upper + self.hw
         if need > self.cap:
-            new_cap = 1 << (need - 1).bit_length()
+            # one sequence: power-of-two capacities keep the workspace ADDRESS (and with it the captured graph) for many
+            # frames, and the kernels get `need`, not the capacity, as row bound.  Several sequences share the row
+            # stride = capacity, which the kernels then scan: grow by 1.5x in 64 Ki-row steps instead, so that the
+            # padding they read stays below half of the data
+            new_cap = 1 << (need - 1).bit_length() if self.B == 1 else -(-max(need, self.cap + self.cap // 2) // 65536) * 65536
             for name in ("points", "normals", "colors", "ccounts"):
                 old = getattr(self, name)
                 if old is None:
