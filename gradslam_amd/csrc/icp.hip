@@ -1289,10 +1289,26 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         // sits up to a pixel further along the row and / or one row further down (rel); what remains is contiguous
         // in row-major order again, so every row band of the tile is ONE slot range.
         // (wave reductions leave uniform values in vector registers: move them, and all that follows, to scalars)
-        const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i(ok ? c - h : 0x7fffffff));
-        const int e = ok ? c - h - dmin : 0;
-        int rel = ok ? (e >= Wd / 2) + (e >= Wd + Wd / 2) : 2;  // rel > 1: no window (a lane that does not move with its tile)
-        const bool in = ok && rel <= 1;
+        // The reference displacement is the MAJORITY's: a lane whose neighbour is far away (no map point near it) has a
+        // centre anywhere, and taking the plain minimum would let one such lane cost the whole tile its windows.  Up to
+        // three candidates (the first lanes not yet represented); supporters = lanes within a row and three columns.
+        const int dsp = c - h;
+        auto near = [&](int r) { return abs(r) <= 3 || abs(r - Wd) <= 3 || abs(r + Wd) <= 3; };
+        const unsigned long long okm = __ballot(ok);
+        unsigned long long pool = okm, sup = 0;
+        for (int tries = 0; tries < 3 && pool; ++tries) {
+            const int cand = __builtin_amdgcn_readlane(dsp, __builtin_ctzll(pool));
+            const unsigned long long m = __ballot(ok && near(dsp - cand));
+            if (__popcll(m) > __popcll(sup)) sup = m;
+            if (2 * __popcll(m) >= __popcll(okm)) break;
+            pool &= ~m;
+        }
+        const bool mine = ok && ((sup >> lane) & 1);
+        const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i(mine ? dsp : 0x7fffffff));
+        const int e = mine ? dsp - dmin : 0;
+        int rel = mine ? (e >= Wd / 2) + (e >= Wd + Wd / 2) : 2;  // rel > 1: no window (a lane that does not move with its tile)
+        const bool in = mine && rel <= 1 && abs(e - rel * Wd) <= 6;
+        if (!in) rel = 2;
         const int beta = c - rel * Wd;
         const int bmin = __builtin_amdgcn_readfirstlane(wave_min_i(in ? beta : 0x7fffffff));
         const int bmax = __builtin_amdgcn_readfirstlane(wave_max_i(in ? beta : (int)0x80000000));
