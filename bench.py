@@ -261,14 +261,18 @@ def aux_c3_full_length(gs, dev, n_frames=200):
     with torch.no_grad():
         for odom in ("icp", "gradicp"):
             slam = gs.slam.PointFusion(odom=odom, dsratio=DS, numiters=ITERS, device=dev)
-            slam(gs.RGBDImages(cd[:, :3], dd[:, :3], Kd, Pd[:, :3]))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            pcs, poses = slam(gs.RGBDImages(cd, dd, Kd, Pd))
-            torch.cuda.synchronize()
-            out["forward_fps_" + odom] = round(n_frames / (time.perf_counter() - t0), 2)
+            best = 0.0
+            for rep in range(2):  # the first pass grows the allocator's pools to the 3.3 M-point arena
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pcs, poses = slam(gs.RGBDImages(cd, dd, Kd, Pd))
+                torch.cuda.synchronize()
+                best = max(best, n_frames / (time.perf_counter() - t0))
+            out["forward_fps_" + odom] = round(best, 2)
         out["final_map_points"] = int(pcs.num_points_per_pointcloud.item())
-    for rep in range(2):  # first pass warms the allocator
+        del pcs, poses
+    for rep in range(3):  # the first passes warm the allocator (7.7 GB of tapes per pass); the last one is reported
+        gc.collect()
         leaves = [x.clone().requires_grad_(True) for x in (cd, dd, Kd, Pd)]
         slam = gs.slam.PointFusion(odom="gradicp", dsratio=DS, numiters=ITERS, device=dev)
         torch.cuda.synchronize()
@@ -280,7 +284,7 @@ def aux_c3_full_length(gs, dev, n_frames=200):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         finite = all(bool(torch.isfinite(x.grad).all()) for x in leaves)
-        del pcs, poses
+        del pcs, poses, leaves, slam
     out.update({"gradicp_fwd_ms_per_frame": round(1e3 * (t1 - t0) / n_frames, 3), "gradicp_bwd_ms_per_frame": round(1e3 * (t2 - t1) / n_frames, 3),
                 "gradicp_fwd_bwd_fps": round(n_frames / (t2 - t0), 2), "grads_finite": finite,
                 "note": "forward: arena-backed sequence driver; forward + backward: one autograd node per sequence (taped arena "

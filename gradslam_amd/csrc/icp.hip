@@ -44,7 +44,7 @@ constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving t
 constexpr int KNN_BT = KNN_NW * 64;
 constexpr int KNN_COARSE = 512; // target points sampled by the seed pass when no seed is given
 constexpr int CHUNK = 16;       // target points per AABB chunk
-constexpr int WROWS = 5;        // grid search: rows of the largest window (radius 2)
+constexpr int WROWS = 3;        // grid search: rows of the window (radius 1; radius 2 = WROWS 5 was measured and bought nothing)
 constexpr int WBANDS = WROWS + 1;  // row bands a tile stages at most (its lanes sit in two adjacent rows)
 constexpr int SUPER = 64;       // chunks per super-box (= 1024 target points = one block of icp_prepare_k)
 constexpr int KNN_LIST = 4096;  // chunk boxes handled per round (capacity of the LDS survivor list)
@@ -1220,6 +1220,7 @@ struct LoopConst {
     int grid_radius_max;   // largest window radius tried (2 or 1)
     float cert_reach2;     // CERT_REACH2, tunable for measurements
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
+    int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a certificate -> every association searches exactly
 };
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
@@ -1338,7 +1339,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             }
             return fits;
         };
-        if (C->grid_radius_max < 2 || !lay_bands(2)) { R = 1; lay_bands(1); }
+        if (C->grid_radius_max < 2 || WROWS < 5 || !lay_bands(2)) { R = 1; lay_bands(1); }
         // staging loads first (they are the long ones), the per-lane rows behind them
         constexpr int ST = KNN_BT - 64, NR = (POOL + ST - 1) / ST;
         float4 sreg[NR];
@@ -1479,7 +1480,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         const float moved = sqrtf(dist2(s, cf.x, cf.y, cf.z));
         const float reach = sqrtf(cf.w) * 0.9999f - moved * 1.0001f;
         // (the same window: same centre by construction, at least the radius the certificate was made with, all of it staged)
-        const bool proven = ((rel & 4) != 0) & ((rel >> 3) >= cert_R) & (cf.w > 0.0f) & (reach > 0.0f) & (bd * 1.0001f < reach * reach);
+        const bool proven = !C->cert_off & ((rel & 4) != 0) & ((rel >> 3) >= cert_R) & (cf.w > 0.0f) & (reach > 0.0f) & (bd * 1.0001f < reach * reach);
         need = ok & !proven;
 #ifdef GS_DIAG_STAMPS
         {   // why certificates fail (diagnostic build): lanes per reason, and the tile's mean radii in micrometres
@@ -1803,9 +1804,10 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     static const int grid_min_env = getenv("GS_GRID_MIN_PER_PIXEL") ? atoi(getenv("GS_GRID_MIN_PER_PIXEL")) : GRID_MIN_PER_PIXEL;
     const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
     static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 1;
+    static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
     const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, hints, gp, thresh, grid_min, grid_rmax,
-                       cert_reach2, 0, 0};
+                       cert_reach2, 0, 0, cert_off};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
