@@ -1245,3 +1245,31 @@ def test_sequence_node_gradients_equal_per_op_nodes(gs, odom):
             assert off <= 12 and e < 5e-2, (odom, name, off, e)
         else:
             assert e < (1e-5 if name == "colors" else 1e-4), (odom, name, e)   # measured: 3e-7 / 2.4e-6 (intrinsics) / 1.8e-7 (poses)
+
+
+def test_sequence_node_edge_cases(gs):
+    """The sequence-level autograd node on the inputs the reference's forward() also accepts: no poses at all (identity
+    start, slam/icpslam.py:128-134), a one-frame sequence, and zero ICP iterations -- same map, poses and gradients as the
+    per-frame formulation."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c0, d0, K0, P0 = make_sequence(1, 3, 60, 80, seed=71)
+    for tag, (L, with_poses, numiters) in {"no_poses": (3, False, 4), "one_frame": (1, True, 4), "zero_iters": (3, True, 0)}.items():
+        res = {}
+        for fused in (True, False):
+            c, dd, K = (x[:, :L].to(DEV).clone().requires_grad_(True) if x.dim() > 4 else x.to(DEV).clone().requires_grad_(True)
+                        for x in (c0, d0, K0))
+            P = P0[:, :L].to(DEV).clone().requires_grad_(True) if with_poses else None
+            slam = gs.slam.PointFusion(odom="gradicp", dsratio=2, numiters=numiters, device=DEV)
+            slam.fused_sequence_autograd = fused
+            pcs, poses = slam(gs.RGBDImages(c, dd, K, P))
+            (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
+            res[fused] = (poses.detach().clone(), pcs.points_list[0].detach().clone(), dd.grad.clone(), K.grad.clone(),
+                          None if P is None else P.grad.clone())
+        a, b = res[True], res[False]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tag
+        off = int(((a[2] - b[2]).abs() > 1e-4 * b[2].abs().max()).sum())
+        assert off <= 12, (tag, off)
+        assert rel_err(a[3].cpu(), b[3].cpu()) < 1e-3, (tag, rel_err(a[3].cpu(), b[3].cpu()))
+        if with_poses:
+            assert rel_err(a[4].cpu(), b[4].cpu()) < 1e-4, tag
