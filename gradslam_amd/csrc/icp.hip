@@ -1258,6 +1258,18 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
         if (step_mode >= 0)
             step_wave0(&st_sm, acc_sm, step_mode, C->gp, pub ? C->trace : nullptr, pub ? C->out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm, true);
+    } else if (!grid && tile_live && !first && wave == 1) {
+        // chunk-box search: the seed (the previous neighbour's target point) for either outcome of the step, fetched
+        // while wave 0 computes it -- two dependent loads less on the association's critical path
+        if (ok) {
+            const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
+            const unsigned long long ka = B.N(ba)[i], kb = B.N(bb)[i];
+            // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
+            const int sa = (int)min((uint32_t)(ka & 0xffffffffu), (uint32_t)(nt - 1)), sb = (int)min((uint32_t)(kb & 0xffffffffu), (uint32_t)(nt - 1));
+            const f3 qa = ld3(C->tgt, sa), qb = ld3(C->tgt, sb);
+            *reinterpret_cast<float4 *>(sh.seed[0][lane]) = make_float4(qa.x, qa.y, qa.z, __int_as_float(sa));
+            *reinterpret_cast<float4 *>(sh.seed[1][lane]) = make_float4(qb.x, qb.y, qb.z, __int_as_float(sb));
+        }
     } else if (grid && tile_live) {
         const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
         const int h = ok ? min(max(C->hints.src_pix[i], 0), nc - 1) : 0;
@@ -1513,11 +1525,15 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         GS_STAMP(3);
     } else {
         int sj = -1;
-        if (!first) {
-            sj = 0;
-            if (ok) {
-                const unsigned long long k = B.N(b_cur)[i];
-                sj = (k == KEY_NONE) ? 0 : min((int)(uint32_t)(k & 0xffffffffu), nt - 1);
+        if (!first) {  // seeded from what wave 1 fetched during the step (knn_tile's -2: keys already in LDS)
+            sj = -2;
+            if (wave == 0) {
+                unsigned long long k0 = KEY_NONE;
+                if (ok) {
+                    const float4 q = *reinterpret_cast<const float4 *>(sh.seed[b_cur == S_in->b_cur ? 0 : 1][lane]);
+                    k0 = pack_key(dist2(s, q.x, q.y, q.z), __float_as_int(q.w));
+                }
+                sh.key[lane] = k0;
             }
         }
         const bool window_seed = first && C->hints.scan_points && C->hints.src_pix && C->hints.pix_start && C->hints.grid_w > 0;
