@@ -1273,3 +1273,32 @@ def test_sequence_node_edge_cases(gs):
         assert rel_err(a[3].cpu(), b[3].cpu()) < 1e-3, (tag, rel_err(a[3].cpu(), b[3].cpu()))
         if with_poses:
             assert rel_err(a[4].cpu(), b[4].cpu()) < 1e-4, tag
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_grid_search_fuzz_against_bruteforce(gs, seed):
+    """Randomised scenes for the grid search with distance certificates: grid shape, density, motion, loop length and
+    LM / gradLM drawn per seed; every association of every loop must be the brute-force scan's, and the loop's result
+    the chunk-box search's."""
+    import random
+
+    rnd = random.Random(1000 + seed)
+    Hd, Wd = rnd.choice([(20, 30), (45, 64), (60, 80), (33, 129), (96, 17)])
+    kw = dict(Hd=Hd, Wd=Wd, per_cell=rnd.choice([2, 5, 9, 20, 33]), motion=rnd.choice([0.001, 0.004, 0.012, 0.03, 0.08]),
+              shuffle_hints=rnd.random() < 0.15, duplicates=rnd.random() < 0.3, with_tgt_pix=rnd.random() < 0.8)
+    sc = _grid_scene(seed=50 + seed, **kw)
+    grad_lm, iters = int(rnd.random() < 0.5), rnd.choice([1, 2, 5, 9])
+    T0 = torch.eye(4)
+    T0[:3, 3] = torch.tensor([rnd.uniform(-0.02, 0.02) for _ in range(3)])
+    res = {}
+    for mode in (2, 0):
+        gs._native.lib().gs_set_grid_search(mode)
+        try:
+            T, assoc = _taped_loop_with_hints(gs, sc, iters, grad_lm, init_T=T0)
+        finally:
+            gs._native.lib().gs_set_grid_search(1)
+        for a, (cloud, keys) in enumerate(assoc):
+            want = gs.ops.knn1_raw(cloud.contiguous(), sc["tgt"], brute_force=True)
+            assert int((keys != want).sum()) == 0, (seed, kw, mode, a)
+        res[mode] = T.clone()
+    assert torch.equal(res[2], res[0]), (seed, kw)
