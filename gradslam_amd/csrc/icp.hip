@@ -1221,6 +1221,7 @@ struct LoopConst {
     float cert_reach2;     // CERT_REACH2, tunable for measurements
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
     int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a certificate -> every association searches exactly
+    int recentre_keep;     // the window follows the neighbour once it is more than this many pixels from the centre (0 / 1)
 };
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
@@ -1558,7 +1559,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             }
             const int cstar = C->hints.tgt_pix ? min(max(C->hints.tgt_pix[(uint32_t)(key & 0xffffffffu)], 0), nc - 1) : centre;
             // the neighbour should sit in the inner part of the window (one pixel of margin to its rim)
-            const int keep = max(R - 1, 1);
+            const int keep = C->recentre_keep;
             const bool inside = abs(cstar / Wd - centre / Wd) <= keep && abs(cstar % Wd - centre % Wd) <= keep;
             *reinterpret_cast<float4 *>(C->cert + 4 * (int64_t)i) = make_float4(s.x, s.y, s.z, (inside && (rel & 4)) ? m_new : 0.0f);
             C->cert_c[i] = (inside ? centre : cstar) | (R << 24);
@@ -1821,9 +1822,10 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
     static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 1;
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
+    static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
     const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, hints, gp, thresh, grid_min, grid_rmax,
-                       cert_reach2, 0, 0, cert_off};
+                       cert_reach2, 0, 0, cert_off, recentre_keep};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);

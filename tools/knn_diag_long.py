@@ -11,6 +11,7 @@ import gradslam_amd as gs
 from gradslam_amd.synthetic import make_sequence
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+numiters = int(sys.argv[2]) if len(sys.argv) > 2 else 10  # < 10: the LAST frame only is cut short, so the last launch is association numiters + 1
 dev = "cuda:0"
 c, d, K, P = make_sequence(1, n, 480, 640, seed=100)
 frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
@@ -21,7 +22,16 @@ dbg = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device=dev)
 assert lib.gs_diag_set_buffer(dbg.data_ptr()) == 0
 slam = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10, device=dev)
 with torch.no_grad():
-    pcs, poses = slam(frames)
+    if numiters == 10:
+        pcs, poses = slam(frames)
+    else:
+        head = gs.RGBDImages(c[:, :n - 1].to(dev), d[:, :n - 1].to(dev), K.to(dev), P[:, :n - 1].to(dev))
+        pcs, poses = slam(head)
+        short = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=numiters, device=dev)
+        dbg.zero_()
+        live = gs.RGBDImages(c[:, n - 1:n].to(dev), d[:, n - 1:n].to(dev), K.to(dev))
+        prevf = gs.RGBDImages(c[:, n - 2:n - 1].to(dev), d[:, n - 2:n - 1].to(dev), K.to(dev), poses[:, n - 2:n - 1].contiguous())
+        short._localize(pcs, live, prevf)
 torch.cuda.synchronize()
 print("frames", n, "map", int(pcs.num_points_per_pointcloud.item()))
 raw = dbg.cpu().numpy().reshape(nblk, 16, 16)
