@@ -359,7 +359,8 @@ __device__ __forceinline__ int sel4(int k, int a0, int a1, int a2, int a3) { ret
 template <bool GRID>
 __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, const bool ok, const bool act,
                                                  const float *__restrict__ scan, const int32_t *__restrict__ scan_orig,
-                                                 const float *__restrict__ boxes, const int nt, const float reach2 = 1.0f) {
+                                                 const float *__restrict__ boxes, const float *__restrict__ sboxes /* or NULL */,
+                                                 const int nt, const float reach2 = 1.0f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int n_scanned = 0;
     // the tile's box (from LDS) and its loosest bound (same 64 points in every wave -> same value)
@@ -382,6 +383,21 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
         const int r1 = min(nchunks, r0 + KNN_LIST);
         // coarse: lanes = chunk boxes; box-to-box gap with the distance's accumulation order
         for (int c0 = r0 + wave * 64; c0 < r1; c0 += KNN_NW * 64) {
+            if (sboxes) {
+                // the 64 chunks of this round are one super-box (c0 is a multiple of SUPER): its box contains theirs, so
+                // its gap to the tile's box is, axis by axis, at most theirs and -- same operation order, monotone
+                // rounding -- its bound at most each of theirs: above the tile's loosest bound, all 64 are pruned at once
+                static_assert(SUPER == 64 && KNN_LIST % SUPER == 0, "one coarse round = one super-box");
+                const float *b = sboxes + 6 * (int64_t)__builtin_amdgcn_readfirstlane(c0 / SUPER);
+                const float ex = fmaxf(fmaxf(b[0] - thx, tlx - b[3]), 0.0f);
+                const float ey = fmaxf(fmaxf(b[1] - thy, tly - b[4]), 0.0f);
+                const float ez = fmaxf(fmaxf(b[2] - thz, tlz - b[5]), 0.0f);
+                const float lbs = (ex * ex + ey * ey) + ez * ez;
+                if (!(lbs <= bdmax)) {
+                    if (GRID) mt = fminf(mt, lbs);
+                    continue;
+                }
+            }
             const int c = c0 + lane;
             bool pass = false;
             if (c < r1) {
@@ -598,7 +614,8 @@ __device__ __forceinline__ void knn_point_search(KnnShared &sh, const f3 s, cons
 __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s, const bool ok, const int seed_j,
                                                        const float *__restrict__ tgt, const float *__restrict__ scan,
                                                        const int32_t *__restrict__ scan_orig,
-                                                       const float *__restrict__ boxes, const int nt) {
+                                                       const float *__restrict__ boxes, const float *__restrict__ sboxes,
+                                                       const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     GS_STAMP(0);
     if (wave == 0 && seed_j != -2) {  // -2: keys already seeded in LDS by knn_window_seed
@@ -646,7 +663,7 @@ __device__ __forceinline__ unsigned long long knn_tile(KnnShared &sh, const f3 s
         }
     }
     GS_STAMP(1);
-    knn_prune_search<false>(sh, s, ok, ok, scan, scan_orig, boxes, nt);
+    knn_prune_search<false>(sh, s, ok, ok, scan, scan_orig, boxes, sboxes, nt);
     GS_STAMP(2);
     GS_STAMP(3);
     return ok ? sh.key[lane] : KEY_NONE;
@@ -693,7 +710,7 @@ __global__ __launch_bounds__(KNN_BT) void knn1_box_k(const float *__restrict__ s
         if (ok && wave == 0) best[i] = KEY_NONE;
         return;
     }
-    const unsigned long long key = knn_tile(sh, s, ok, -1, tgt, tgt, nullptr, boxes, nt);
+    const unsigned long long key = knn_tile(sh, s, ok, -1, tgt, tgt, nullptr, boxes, nullptr, nt);
     if (ok && wave == 0) best[i] = key;
 }
 
@@ -748,6 +765,7 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
 // Fixed-order reduction of the per-block partials by a 1024-thread block into acc_sm[NACC]:
 // thread (g, k) = (t / 32, t % 32) sums rows g, g+32, g+64, ... of accumulator k (coalesced over k),
 // then 29 threads add the 32 group sums in order.  Two short LDS stages, no shuffle chains.
+constexpr int RP_LOADS = 16;  // reduce_partials: loads in flight per thread
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -761,19 +779,20 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
     float v = 0.0f;
     {
         // The rows were written by the previous launch on other CUs: every read is a trip to memory-side
-        // cache (~1.5 us), so what matters is how many of them are in flight -- ten per thread and round.
+        // cache (~1.5 us), so what matters is how many of them are in flight -- sixteen per thread and round: the 512
+        // rows of a full chip (two tiles per CU) in ONE round.
         bool hooked = false;
-        for (int b0 = g; b0 < nblocks || !hooked; b0 += 320) {
-            float a[10];
+        for (int b0 = g; b0 < nblocks || !hooked; b0 += 32 * RP_LOADS) {
+            float a[RP_LOADS];
 #pragma unroll
-            for (int u = 0; u < 10; ++u) {
+            for (int u = 0; u < RP_LOADS; ++u) {
                 const int b = b0 + 32 * u;
                 a[u] = (k < NACC && b < nblocks) ? partials[b * NACC + k] : 0.0f;
             }
             if (!hooked) after_issue();
             hooked = true;
 #pragma unroll
-            for (int u = 0; u < 10; ++u) v += a[u];
+            for (int u = 0; u < RP_LOADS; ++u) v += a[u];
         }
     }
     stage[k][g] = v;
@@ -1222,6 +1241,7 @@ struct LoopConst {
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
     int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a certificate -> every association searches exactly
     int recentre_keep;     // the window follows the neighbour once it is more than this many pixels from the centre (0 / 1)
+    int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each): loop_tile_points()
 };
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
@@ -1236,9 +1256,9 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     GS_STAMP(6);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ns = C->ns, nt = C->nt;
-    const int tile0 = blockIdx.x * 64;
+    const int tile0 = blockIdx.x * C->tile_points;
     const int i = tile0 + lane;
-    const bool ok = i < ns;
+    const bool ok = lane < C->tile_points && i < ns;
     const bool tile_live = tile0 < ns && nt > 0;
     // The grid search pays where pixels hold several targets (a map that has seen many frames): chunk C->boxes are
     // compact there and neighbour distances small against the pixel pitch, so certificates hold from the second
@@ -1514,8 +1534,18 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         if (__popcll(need_mask) > 6) {
             tile_box(sh, s, need);
             __syncthreads();
-            knn_prune_search<true>(sh, s, ok, need, C->hints.scan_points, C->hints.scan_orig, C->boxes, nt, C->cert_reach2);  // ends with a barrier
+            knn_prune_search<true>(sh, s, ok, need, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt, C->cert_reach2);  // ends with a barrier
             m_new = fminf(bitsf(sh.mm[lane]), bitsf(sh.m_tile));
+#ifdef GS_DIAG_STAMPS
+            {   // which of the two radii decides the certificate, and how large they are (micrometres, tile means)
+                const float mt_ = bitsf(sh.m_tile), ml_ = bitsf(sh.mm[lane]);
+                const unsigned long long n_tile = __popcll(__ballot(need & (mt_ < ml_)));
+                const float nn = fmaxf((float)__popcll(need_mask), 1.0f);
+                const unsigned long long um_t = (unsigned long long)fminf(1e6f * sqrtf(mt_), 1e6f),
+                                         um_l = (unsigned long long)fminf(1e6f * wave_sum(need ? fminf(sqrtf(ml_), 1.0f) : 0.0f) / nn, 1e6f);
+                GS_COUNT(15, n_tile | (um_t << 8) | (um_l << 32));
+            }
+#endif
         } else if (need_mask) {
             knn_point_search(sh, s, need_mask, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt,
                              C->cert_reach2 * wave_max_f(ok ? bd : 0.0f));  // ends with a barrier
@@ -1542,7 +1572,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         const float *scan = C->hints.scan_points ? C->hints.scan_points : C->tgt;
         const int32_t *scan_orig = C->hints.scan_points ? C->hints.scan_orig : nullptr;
         if (window_seed) knn_window_seed(sh, s, ok, i, C->hints, nt);
-        key = knn_tile(sh, s, ok, sj, C->tgt, scan, scan_orig, C->boxes, nt);
+        key = knn_tile(sh, s, ok, sj, C->tgt, scan, scan_orig, C->boxes, C->sboxes, nt);
     }
     // linearise this tile straight away (J fused into K's epilogue): 29 sums over the tile's 64 points,
     // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
@@ -1717,6 +1747,28 @@ static inline void prof_mark(int tag, int which, hipStream_t st) {
 bool profiling_enabled() { return g_prof.on; }
 
 static int g_grid_mode = 1;  // gs_set_grid_search
+static int g_tile_points = 0;  // gs_set_tile_points (0 = automatic)
+
+// Source points per block of the loops' association kernel (knn1_loop_k).  A 1024-thread block is one co-residency
+// unit: a CU holds two.  With 64-point tiles a 160 x 120 ds-grid is ~290 blocks on 256 CUs -- some CUs host two
+// full-rate blocks, most host one, and the launch lasts as long as the doubled ones (the search is VALU-issue bound).
+// Between one and two blocks per CU the tile shrinks instead, so that EVERY CU hosts two smaller tiles: the same
+// block, lanes tile_points .. 63 idle, fewer surviving chunk boxes per tile.  The tile size fixes the order of the
+// 29-term sums (per tile, then over tiles), so it depends on max_ns and the target's density alone -- never on the
+// search variant (gs_set_grid_search): grid search and chunk-box search stay bit-identical.
+constexpr int TILE_MIN = 32;
+static inline int loop_tile_points(int max_ns, bool dense) {
+    static const int env = getenv("GS_TILE_POINTS") ? atoi(getenv("GS_TILE_POINTS")) : 0;
+    const int forced = g_tile_points ? g_tile_points : env;
+    if (forced >= TILE_MIN && forced <= 64) return forced;
+    const int b64 = cdiv(max_ns, 64);
+    // measured (MI355X, 160 x 120 ds-grid): on a dense target (200-frame map, search-bound launches) 38-point tiles
+    // give 1 248 against 1 178 frames/s; on the sparse single-frame target of the c2 step (latency-bound launches)
+    // 506 blocks cost 20.7 us per launch against 18.8 for 300 -- so only where the target is dense
+    if (!dense || b64 <= 256 || b64 > 2 * 256) return 64;
+    return max(TILE_MIN, cdiv(max_ns, 2 * 256));
+}
+static inline int loop_blocks_max(int max_ns) { return cdiv(max_ns, TILE_MIN); }  // workspace: whatever the tile size
 
 struct IcpWs {
     IcpState *S[2];      // double-buffered across launches (see knn1_loop_k)
@@ -1733,7 +1785,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oS = take(sizeof(IcpState)), oS1 = take(sizeof(IcpState));
     const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
-    const size_t oPart = take((size_t)cdiv(max_ns, 64) * NACC * 4), oPart1 = take((size_t)cdiv(max_ns, 64) * NACC * 4);
+    const size_t oPart = take((size_t)loop_blocks_max(max_ns) * NACC * 4), oPart1 = take((size_t)loop_blocks_max(max_ns) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt)), oSBox = take((size_t)cdiv(max_nt > 0 ? max_nt : 1, 1024) * 6 * 4);
     const size_t oCert = take((size_t)max_ns * 16), oCertC = take((size_t)max_ns * 4), oLc = take(sizeof(LoopConst));
     if (ws && out) {
@@ -1814,18 +1866,22 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         w.B = tp.B;  // the tape is the loop's working storage
     }
     int n_assoc = 0, n_step = 0;
-    const dim3 kgrid(cdiv(max_ns, 64));
-    const int lb = (int)kgrid.x;  // one partial row per 64-point tile, written by the association kernel
+    static const int grid_min_env = getenv("GS_GRID_MIN_PER_PIXEL") ? atoi(getenv("GS_GRID_MIN_PER_PIXEL")) : GRID_MIN_PER_PIXEL;
+    // dense target (several points per ds-grid pixel: a map that has seen many frames), by the caller's word or by size
+    const bool dense = hints.grid_w > 0 && hints.grid_h > 0 && dense_hint != 0 &&
+                       (dense_hint > 0 || (int64_t)max_nt >= (int64_t)grid_min_env * hints.grid_w * hints.grid_h);
+    const int tile_points = loop_tile_points(max_ns, dense);
+    const dim3 kgrid(cdiv(max_ns, tile_points));
+    const int lb = (int)kgrid.x;  // one partial row per tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
 
-    static const int grid_min_env = getenv("GS_GRID_MIN_PER_PIXEL") ? atoi(getenv("GS_GRID_MIN_PER_PIXEL")) : GRID_MIN_PER_PIXEL;
     const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
     static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 1;
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
     static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
     const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, hints, gp, thresh, grid_min, grid_rmax,
-                       cert_reach2, 0, 0, cert_off, recentre_keep};
+                       cert_reach2, 0, 0, cert_off, recentre_keep, tile_points};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
@@ -1846,8 +1902,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     // ... and only where the target can be dense enough for it (the kernel checks the actual count again): the grid
     // variant carries more registers and 32 bytes of scratch, 1.4 us per launch on a sparse target
     const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
-                             hints.grid_w > 0 && hints.grid_h > 0 &&
-                             (g_grid_mode == 2 || (dense_hint != 0 && (dense_hint > 0 || (int64_t)max_nt >= (int64_t)grid_min * hints.grid_w * hints.grid_h)));
+                             hints.grid_w > 0 && hints.grid_h > 0 && (g_grid_mode == 2 || dense);
     auto assoc = [&](int first) {
         if (!fold && pending >= 0) {  // stand-alone step, state updated in place
             hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S[cur], w.partials[cur], lb, pending, gp, trace, out_T,
@@ -2358,6 +2413,7 @@ int gs_diag_set_buffer(void *p) {
 #endif
 
 void gs_set_grid_search(int on) { g_grid_mode = on; }
+void gs_set_tile_points(int n) { g_tile_points = n; }
 
 void gs_profile_enable(int on) {
     g_prof.on = on != 0;

@@ -1054,6 +1054,35 @@ def test_grid_search_every_association_is_the_bruteforce_scan(gs, case):
     assert torch.equal(T, T_grid)
 
 
+@pytest.mark.parametrize("case,tile", [("plain", 33), ("big_motion_dense", 38), ("two_rows_per_tile", 48), ("duplicates", 47), ("gradlm", 40)])
+def test_tile_points_every_association_is_the_bruteforce_scan(gs, case, tile):
+    """Tiles of fewer than 64 source points per block (gs_set_tile_points; chosen automatically where every CU can host
+    two of them): every association of the loop is still the brute-force scan's, with either search, and the pose
+    agrees with the 64-point tiling to rounding (the tile size fixes the summation order of the 6x6 system)."""
+    kw = dict(plain={}, big_motion_dense=dict(motion=0.05, per_cell=24, Hd=40, Wd=60), duplicates=dict(duplicates=True), gradlm={},
+              two_rows_per_tile=dict(Hd=90, Wd=24, motion=0.03))[case]
+    sc = _grid_scene(seed=len(case), **kw)
+    grad_lm = 1 if case == "gradlm" else 0
+    lib = gs._native.lib()
+    res = {}
+    for tp in (tile, 64):
+        for mode in (2, 0):
+            lib.gs_set_grid_search(mode)
+            lib.gs_set_tile_points(tp)
+            try:
+                T, assoc = _taped_loop_with_hints(gs, sc, 6, grad_lm)
+            finally:
+                lib.gs_set_grid_search(1)
+                lib.gs_set_tile_points(0)
+            for a, (cloud, keys) in enumerate(assoc):
+                want = gs.ops.knn1_raw(cloud.contiguous(), sc["tgt"], brute_force=True)
+                bad = (keys != want).sum().item()
+                assert bad == 0, (case, tp, mode, a, bad)
+            res[(tp, mode)] = T.clone()
+        assert torch.equal(res[(tp, 2)], res[(tp, 0)])  # same tiling: same sums, whatever the search
+    assert (res[(tile, 2)] - res[(64, 2)]).abs().max().item() < 2e-5, (res[(tile, 2)] - res[(64, 2)]).abs().max().item()
+
+
 def test_grid_search_sequence_equals_chunk_search(gs):
     """A 25-frame PointFusion run (map and ICP target growing, several targets per pixel) with the grid search on and
     off: poses and map bit for bit."""

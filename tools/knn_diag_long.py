@@ -65,6 +65,12 @@ print("tile with most lanes in need (%d): not fully staged %d | smaller radius %
       "tile means (mm): sqrt(m) %.1f moved %.1f sqrt(bd) %.1f" % (need[worst], f(why[worst], 0), f(why[worst], 8), f(why[worst], 16), f(why[worst], 24), f(why[worst], 32),
       f(why[worst], 40), (rad[worst] & 0xfffff) / 1e3, ((rad[worst] >> 20) & 0xfffff) / 1e3, ((rad[worst] >> 40) & 0xfffff) / 1e3))
 print("all tiles: lanes per reason (sum): not staged %d | radius %d | no certificate %d | moved %d | reach %d" % tuple(int(((why >> sh) & 0xff).sum()) for sh in (0, 8, 16, 24, 32)))
+w15 = raw[live][:, 0, 15]
+sel = w15 != 0
+if sel.any():
+    print("fresh certificates (tiles that ran the tile-level search: %d): lanes whose radius is the TILE-level bound: mean %.1f per tile ; "
+          "sqrt(m_tile) mean %.1f mm ; mean per-lane sqrt(mm) %.1f mm" % (int(sel.sum()), (w15[sel] & 0xff).mean(), ((w15[sel] >> 8) & 0xffffff).mean() / 1e3,
+          ((w15[sel] >> 32) & 0xffffff).mean() / 1e3))
 print("coarse us per wave p50 %.2f p99 %.2f | fine us p50 %.2f p99 %.2f | barrier waits us p50 %.2f p99 %.2f | survivors tested per wave p50 %.0f" % (
     *pc(a[..., 8] * tick, [50, 99]), *pc(a[..., 9] * tick, [50, 99]), *pc(a[..., 10] * tick, [50, 99]), np.percentile(a[..., 11], 50)))
 print("chunks scanned per block: mean %.1f max %d ; coarse survivors per block mean %.1f max %d" % (
