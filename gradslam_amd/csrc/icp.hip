@@ -1241,7 +1241,10 @@ struct LoopConst {
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
     int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a certificate -> every association searches exactly
     int recentre_keep;     // the window follows the neighbour once it is more than this many pixels from the centre (0 / 1)
-    int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each): loop_tile_points()
+    int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each).  The host
+                           // hands in the size for a DENSE target (loop_tile_points); icp_prepare_k replaces it by 64 when
+                           // the target's actual count says sparse -- a decision made from device-side counts only
+    int dense_min_per_pixel;  // ... dense = at least this many targets per ds-grid pixel on average (0: whatever the count)
 };
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
@@ -1260,6 +1263,13 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     const int i = tile0 + lane;
     const bool ok = lane < C->tile_points && i < ns;
     const bool tile_live = tile0 < ns && nt > 0;
+    // The launch holds enough blocks for the smallest tile size; on a sparse target (64-point tiles) the surplus ones
+    // leave at once.  Their partial rows are zeros at the END of every thread's summation sequence in reduce_partials:
+    // the sums are bit for bit those of a launch without them.  (Block 0 publishes the state: it always stays.)
+    if (tile0 >= ns && blockIdx.x != 0) {
+        if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
+        return;
+    }
     // The grid search pays where pixels hold several targets (a map that has seen many frames): chunk C->boxes are
     // compact there and neighbour distances small against the pixel pitch, so certificates hold from the second
     // association on.  On a sparse target (about one per pixel: C->boxes 16 pixels long, neighbours half a pixel away)
@@ -1271,7 +1281,8 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     // row bands of the tile, stage the bands' targets into LDS and fetch the seed for either outcome of the step.
     // Nothing of that depends on the step, so it costs the association no time.
     if (step_mode >= 0) {
-        reduce_partials(partials_in, nblocks_in, acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
+        // (rows of surplus blocks -- see above -- are zeros behind every thread's last live row: not read)
+        reduce_partials(partials_in, min(nblocks_in, (ns + C->tile_points - 1) / C->tile_points), acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
         // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
         if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
     }
@@ -1642,6 +1653,11 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
         int v = reinterpret_cast<const int *>(&lc)[threadIdx.x];
         if (threadIdx.x == offsetof(LoopConst, ns) / 4) v = *lc.d_ns;
         if (threadIdx.x == offsetof(LoopConst, nt) / 4) v = *lc.d_nt;
+        if (threadIdx.x == offsetof(LoopConst, tile_points) / 4) {
+            const int64_t pixels = (int64_t)lc.hints.grid_w * lc.hints.grid_h;
+            const bool dense = lc.dense_min_per_pixel == 0 || (pixels > 0 && (int64_t)*lc.d_nt >= lc.dense_min_per_pixel * pixels);
+            v = dense ? lc.tile_points : 64;
+        }
         reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1751,23 +1767,28 @@ static int g_tile_points = 0;  // gs_set_tile_points (0 = automatic)
 
 // Source points per block of the loops' association kernel (knn1_loop_k).  A 1024-thread block is one co-residency
 // unit: a CU holds two.  With 64-point tiles a 160 x 120 ds-grid is ~290 blocks on 256 CUs -- some CUs host two
-// full-rate blocks, most host one, and the launch lasts as long as the doubled ones (the search is VALU-issue bound).
-// Between one and two blocks per CU the tile shrinks instead, so that EVERY CU hosts two smaller tiles: the same
-// block, lanes tile_points .. 63 idle, fewer surviving chunk boxes per tile.  The tile size fixes the order of the
-// 29-term sums (per tile, then over tiles), so it depends on max_ns and the target's density alone -- never on the
-// search variant (gs_set_grid_search): grid search and chunk-box search stay bit-identical.
+// full-rate blocks, most host one, and on a dense target (search-bound launches, VALU-issue bound) the launch lasts as
+// long as the doubled ones.  Between one and two blocks per CU the tile shrinks instead, so that EVERY CU hosts two
+// smaller tiles: the same block, lanes tile_points .. 63 idle, fewer surviving chunk boxes per tile.  Measured
+// (MI355X, 160 x 120 ds-grid): 38-point tiles give 1 248 against 1 178 frames/s over 200 frames; on the sparse
+// single-frame target of the c2 step (latency-bound launches) they cost 20.7 us per launch against 18.8 -- so the
+// small tiles are for dense targets only.
+// The tile size fixes the order of the 29-term sums (per tile, then over tiles), so it must be a function of the
+// DATA: the host launches enough blocks for the small tiles whenever max_ns is in the range, and icp_prepare_k picks
+// 64 or the small size from the target's actual count on the device (LoopConst::tile_points).  The host's own idea of
+// the density (an upper bound of the map size that depends on when asynchronous read-backs land) only selects the
+// search variant, which never changes a bit of the result.
 constexpr int TILE_MIN = 32;
-static inline int loop_tile_points(int max_ns, bool dense) {
+static inline int loop_tile_points(int max_ns, bool have_grid, bool *forced_out) {
     static const int env = getenv("GS_TILE_POINTS") ? atoi(getenv("GS_TILE_POINTS")) : 0;
     const int forced = g_tile_points ? g_tile_points : env;
-    if (forced >= TILE_MIN && forced <= 64) return forced;
+    *forced_out = forced >= TILE_MIN && forced <= 64;
+    if (*forced_out) return forced;
     const int b64 = cdiv(max_ns, 64);
-    // measured (MI355X, 160 x 120 ds-grid): on a dense target (200-frame map, search-bound launches) 38-point tiles
-    // give 1 248 against 1 178 frames/s; on the sparse single-frame target of the c2 step (latency-bound launches)
-    // 506 blocks cost 20.7 us per launch against 18.8 for 300 -- so only where the target is dense
-    if (!dense || b64 <= 256 || b64 > 2 * 256) return 64;
+    if (!have_grid || b64 <= 256 || b64 > 2 * 256) return 64;
     return max(TILE_MIN, cdiv(max_ns, 2 * 256));
 }
+int icp_config_stamp() { return g_grid_mode | (g_tile_points << 4); }  // part of slam.hip's graph-cache key
 static inline int loop_blocks_max(int max_ns) { return cdiv(max_ns, TILE_MIN); }  // workspace: whatever the tile size
 
 struct IcpWs {
@@ -1870,8 +1891,9 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     // dense target (several points per ds-grid pixel: a map that has seen many frames), by the caller's word or by size
     const bool dense = hints.grid_w > 0 && hints.grid_h > 0 && dense_hint != 0 &&
                        (dense_hint > 0 || (int64_t)max_nt >= (int64_t)grid_min_env * hints.grid_w * hints.grid_h);
-    const int tile_points = loop_tile_points(max_ns, dense);
-    const dim3 kgrid(cdiv(max_ns, tile_points));
+    bool tile_forced = false;
+    const int tile_points = loop_tile_points(max_ns, hints.grid_w > 0 && hints.grid_h > 0, &tile_forced);
+    const dim3 kgrid(cdiv(max_ns, tile_points));  // enough for the small tiles; on a sparse target the surplus blocks leave at once
     const int lb = (int)kgrid.x;  // one partial row per tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
 
@@ -1881,7 +1903,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
     const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, hints, gp, thresh, grid_min, grid_rmax,
-                       cert_reach2, 0, 0, cert_off, recentre_keep, tile_points};
+                       cert_reach2, 0, 0, cert_off, recentre_keep, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);

@@ -22,9 +22,11 @@ struct GraphKey {
     void *ws;
     int B, capS, capT, numiters, use_grad;
     float damp, thresh, lmax, Bp, B2, nu;
+    int dense, icp_cfg;  // what else decides WHICH kernels a loop launches: the density hint, gs_set_grid_search / _tile_points
     bool operator==(const GraphKey &o) const {
         return ws == o.ws && B == o.B && capS == o.capS && capT == o.capT && numiters == o.numiters && use_grad == o.use_grad &&
-               damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu;
+               damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu && dense == o.dense &&
+               icp_cfg == o.icp_cfg;
     }
 };
 struct GraphEntry {
@@ -72,6 +74,7 @@ int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max
                      const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
                      float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
                      void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint);
+int icp_config_stamp();  // icp.hip: the process-wide search / tiling switches, as one number
 // the ICP target holds about Nmax / ds^2 of the map's points: dense (several per ds-grid pixel) once the map has
 // seen a few frames -- what selects the grid search (icp.hip)
 static inline int target_dense(int Nmax, int H, int W, int ds) {
@@ -384,7 +387,8 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
         std::lock_guard<std::mutex> lock(g_graph_mu);
         int device = 0;
         (void)hipGetDevice(&device);
-        const GraphKey key{ws, B, capS, capT, numiters, use_grad_lm, damp, dist_thresh, lambda_max, Bp, B2, nu};
+        const GraphKey key{ws, B, capS, capT, numiters, use_grad_lm, damp, dist_thresh, lambda_max, Bp, B2, nu,
+                           target_dense(Nmax, H, W, ds), icp_config_stamp()};
         GraphEntry *hit = nullptr;
         for (auto &e : g_graphs)
             if (e.device == device && e.key == key) hit = &e;
