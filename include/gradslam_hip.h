@@ -397,11 +397,13 @@ int gs_profile_read(int tag, long *launches, double *total_ms);
  * reference (chamferdist.knn_points has no such switch); for measurements and tests. */
 void gs_set_grid_search(int on);
 
-/* Source points per 1024-thread block of the loops' association kernel: 0 (default) = automatic (64, or fewer where
- * that lets every CU host two equal tiles instead of some CUs two and most one: max_ns between 16 385 and 32 768),
- * 32 .. 64 = that many.  The tile size fixes the summation order of the 6x6 system, so results of different settings
- * agree to rounding, not bit for bit; nearest neighbours are the brute-force scan's under every setting.  Replaces
- * nothing in the reference; for measurements and tests. */
+/* Source points per 1024-thread block of the loops' association kernel: 0 (default) = automatic -- 64, or
+ * ceil(max_ns / 512) where max_ns lies between 16 385 and 32 768, search hints are given and the target holds at
+ * least four points per ds-grid pixel (decided on the device from the target's count, so the choice is a function
+ * of the data: every CU then hosts two equal tiles instead of some CUs two and most one); 32 .. 64 = that many,
+ * whatever the density.  The tile size fixes the summation order of the 6x6 system, so results of different
+ * settings agree to rounding, not bit for bit; nearest neighbours are the brute-force scan's under every setting.
+ * Replaces nothing in the reference; for measurements and tests. */
 void gs_set_tile_points(int n);
 
 /* ---------------------------------------------------------------- C+U: fusion correspondences

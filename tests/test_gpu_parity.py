@@ -644,6 +644,31 @@ def test_graph_replay_equals_eager_on_a_growing_map(gs):
     assert rel_err(out[1][0].cpu(), P) < 5e-2  # and it is a sane trajectory
 
 
+def test_sequence_is_reproducible_and_graph_equals_eager_640x480(gs):
+    """60 frames of 640x480 PointFusion, four runs in one process (eager, graph replay, graph replay, eager): poses and
+    map bit for bit.  On the way the ICP target crosses the density at which the association kernel switches to smaller
+    tiles (a different summation order): that switch must follow the DATA -- decided on the device from the target's
+    count -- and not the host's upper bound of the map size, which depends on when asynchronous read-backs land
+    (profiles/r02c_graph_vs_eager_determinism.txt: what a host-side decision did)."""
+    from gradslam_amd.synthetic import make_sequence
+
+    c, dd, K, P = make_sequence(1, 60, 480, 640, seed=100)
+    frames = gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV))
+    out = []
+    try:
+        for mode in (0, 1, 1, 0):
+            gs._native.lib().gs_set_graph_mode(mode)
+            slam = gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10, device=DEV)
+            with torch.no_grad():
+                pcs, poses = slam(frames)
+            out.append((poses.clone(), pcs.points_list[0].clone()))
+    finally:
+        gs._native.lib().gs_set_graph_mode(-1)
+    assert out[0][1].shape[0] > 1300000  # dense by the end: > 4 targets per ds-grid pixel in the ICP target
+    for k in (1, 2, 3):
+        assert torch.equal(out[0][0], out[k][0]) and torch.equal(out[0][1], out[k][1]), k
+
+
 # ------------------------------------------------------------------ BASELINE sizes: properties
 def test_full_size_properties(gs):
     """640x480: size-independent properties (the oracle would take minutes here)."""
