@@ -2436,6 +2436,15 @@ int gs_diag_set_buffer(void *p) {
 
 void gs_set_grid_search(int on) { g_grid_mode = on; }
 void gs_set_tile_points(int n) { g_tile_points = n; }
+int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_points_dense, int *partial_rows) {
+    GS_REQUIRE(max_ns > 0, "gs_icp_launch_geometry: max_ns must be positive");
+    bool forced = false;
+    const int tp = loop_tile_points(max_ns, have_hints != 0, &forced);
+    if (blocks) *blocks = cdiv(max_ns, tp);
+    if (tile_points_dense) *tile_points_dense = tp;
+    if (partial_rows) *partial_rows = loop_blocks_max(max_ns);
+    return GS_OK;
+}
 
 void gs_profile_enable(int on) {
     g_prof.on = on != 0;

@@ -405,6 +405,10 @@ void gs_set_grid_search(int on);
  * settings agree to rounding, not bit for bit; nearest neighbours are the brute-force scan's under every setting.
  * Replaces nothing in the reference; for measurements and tests. */
 void gs_set_tile_points(int n);
+/* Launch geometry of one association launch of the loops above for a source capacity (host-side query, no device
+ * work): blocks launched, source points per block on a dense target, and the number of partial rows the workspace
+ * (gs_icp_ws_bytes) holds per buffer (>= blocks for every tile-size setting). */
+int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_points_dense, int *partial_rows);
 
 /* ---------------------------------------------------------------- C+U: fusion correspondences
  * find_similar_map_points (slam/fusionutils.py:381-401): keep[i] = |Vg(b,h,w) - p(b,n)| < dist_th

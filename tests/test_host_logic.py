@@ -32,6 +32,39 @@ def test_library_exports_every_declared_symbol():
     assert lib.gs_abi_version() == 2
 
 
+def test_icp_launch_geometry_fits_the_workspace():
+    """The loops' association launch (host-side rule, no device work): 64-point tiles, or -- with search hints, between
+    one and two 64-point blocks per CU -- enough blocks for tiles small enough that 512 of them cover the cloud; the
+    workspace holds a partial row for every block under every tile-size setting."""
+    import ctypes
+
+    lib = _native.lib()
+
+    def geom(max_ns, hints):
+        b, t, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.gs_icp_launch_geometry(max_ns, hints, ctypes.byref(b), ctypes.byref(t), ctypes.byref(r)) == 0
+        return b.value, t.value, r.value
+
+    assert geom(19200, 1) == (506, 38, 600)          # 160 x 120 ds-grid: every CU two equal tiles
+    assert geom(19200, 0)[:2] == (300, 64)            # no hints: no density to go by
+    assert geom(16384, 1)[:2] == (256, 64)            # one block per CU already
+    assert geom(16385, 1)[:2] == (497, 33)
+    assert geom(32768, 1)[:2] == (512, 64)
+    assert geom(78408, 1)[:2] == (1226, 64)           # more blocks than the chip holds: 64-point tiles, unfolded steps
+    try:
+        for forced in (0, 32, 47, 64):
+            lib.gs_set_tile_points(forced)
+            for max_ns in (1, 63, 64, 65, 4800, 16385, 19200, 32768, 100000):
+                for hints in (0, 1):
+                    blocks, tile, rows = geom(max_ns, hints)
+                    assert 32 <= tile <= 64 and blocks * tile >= max_ns and blocks <= rows, (forced, max_ns, hints)
+                    if forced:
+                        assert tile == forced
+    finally:
+        lib.gs_set_tile_points(0)
+    assert lib.gs_icp_launch_geometry(0, 1, None, None, None) != 0  # error contract: positive capacity
+
+
 def test_integration_notes_cover_every_entry_point():
     """INTEGRATION.md (the reference-side binding notes) names every symbol the header declares."""
     notes = open(os.path.join(REPO, "INTEGRATION.md")).read()
