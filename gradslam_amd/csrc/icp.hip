@@ -9,7 +9,8 @@
 //      (source tiles) x (target ranges) and merged with one 64-bit atomic min on the packed key dist_bits<<32 | index.
 //    * knn1_box_k / knn1_loop_k<false> (chunk-box search): the same pairs, minus those that provably cannot win.
 //      Target points are grouped in chunks of CHUNK = 16 consecutive points with an AABB each.  One 1024-thread
-//      block serves one tile of 64 source points: every wave holds the same 64 points (lane = point) and the 16 waves
+//      block serves one tile of up to 64 source points (in the loops 64, or fewer on a dense target: loop_tile_points):
+//      every wave holds the same points (lane = point) and the 16 waves
 //      share the target chunks -- a coarse pass (lanes = chunk boxes, against the tile's box and loosest bound), then
 //      per-lane bounds ((ex^2+ey^2)+ez^2, e = per-axis gap to the box) and scans with candidates broadcast by
 //      v_readlane.  Rounding is monotone and the bound uses the distance's own operation order, so bound <= distance
