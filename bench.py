@@ -470,9 +470,8 @@ def main():
             "roofline_timed_region": {
                 "kernel": "knn1_loop_k (X+K+J fused: the previous iteration's O(1) step -- reduce, LM decision, 6x6 solve, exp -- "
                           "on wave 0, then rigid transform, exact 1-NN association with fp32-exact AABB pruning, "
-                          "Jacobian rows and 29-term reduce of its 64-point tile; launched as 506 blocks of which the 206 "
-                          "beyond the cloud leave at once -- the tile size, 64 here and 38 on a dense target, is decided on the "
-                          "device from the target's count)",
+                          "Jacobian rows and 29-term reduce of its 64-point tile -- 38-point tiles on a dense target of a long "
+                          "sequence, decided on the device from the target's and the map's counts)",
                 "launches": n_knn, "avg_launch_ms": round(avg_knn_ms, 5),
                 "timing_source": "HIP events on the launch stream, second eager pass of {} steps".format(n_prof),
                 "hbm_view": {"algorithmic_bytes_per_launch": 40.0 * ns, "achieved_GBps": round(40.0 * ns / (avg_knn_ms * 1e-3) / 1e9, 2)

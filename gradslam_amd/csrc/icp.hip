@@ -1233,6 +1233,7 @@ struct LoopConst {
     const int32_t *d_ns, *d_nt;
     float *trace, *out_T, *cert;
     int32_t *cert_c;
+    const int32_t *guard_count;  // small tiles only if ALSO *guard_count >= guard_min (the map's actual size; NULL: no such guard)
     gs_icp_hints hints;
     GradParams gp;
     float thresh;
@@ -1246,6 +1247,8 @@ struct LoopConst {
                            // hands in the size for a DENSE target (loop_tile_points); icp_prepare_k replaces it by 64 when
                            // the target's actual count says sparse -- a decision made from device-side counts only
     int dense_min_per_pixel;  // ... dense = at least this many targets per ds-grid pixel on average (0: whatever the count)
+    int guard_min;
+    int loop_blocks;          // blocks of every association launch of this loop (the small tiles must cover the cloud)
 };
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
@@ -1657,7 +1660,9 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
         if (threadIdx.x == offsetof(LoopConst, tile_points) / 4) {
             const int64_t pixels = (int64_t)lc.hints.grid_w * lc.hints.grid_h;
             const bool dense = lc.dense_min_per_pixel == 0 || (pixels > 0 && (int64_t)*lc.d_nt >= lc.dense_min_per_pixel * pixels);
-            v = dense ? lc.tile_points : 64;
+            const bool guard = lc.guard_count == nullptr || *lc.guard_count >= lc.guard_min;
+            const bool covers = (int64_t)lc.loop_blocks * lc.tile_points >= (int64_t)*lc.d_ns;  // (by construction; never relied on)
+            v = (dense && guard && covers) ? lc.tile_points : 64;
         }
         reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
     }
@@ -1857,7 +1862,8 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
                    GradParams gp, const gs_icp_hints *hints_in, float *out_T, uint64_t *best_last, float *trace, void *ws,
                    size_t ws_bytes, hipStream_t st, const char *name, void *tape = nullptr, size_t tape_bytes = 0,
                    const float *compose_right = nullptr, float *compose_out = nullptr,
-                   int dense_hint = -1 /* caller's knowledge of the target's density: 1 dense, 0 sparse, -1 judge by max_nt */) {
+                   int dense_hint = -1 /* caller's knowledge of the target's density: 1 dense, 0 sparse, -1 judge by max_nt */,
+                   const int32_t *guard_count = nullptr, int guard_min = 0 /* see LoopConst::guard_count */) {
     gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
@@ -1893,7 +1899,11 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const bool dense = hints.grid_w > 0 && hints.grid_h > 0 && dense_hint != 0 &&
                        (dense_hint > 0 || (int64_t)max_nt >= (int64_t)grid_min_env * hints.grid_w * hints.grid_h);
     bool tile_forced = false;
-    const int tile_points = loop_tile_points(max_ns, hints.grid_w > 0 && hints.grid_h > 0, &tile_forced);
+    // A caller that hands in the map's count (gs_slam_localize) promises dense_hint != 0 whenever that count reaches
+    // guard_min (its bound Nmax is never below the count): only then can the device choose the small tiles, so a launch
+    // whose bound says "cannot be dense" (the c2 step on a one-frame map) carries no surplus blocks.
+    const bool small_geometry = hints.grid_w > 0 && hints.grid_h > 0 && (guard_count == nullptr || dense_hint != 0);
+    const int tile_points = loop_tile_points(max_ns, small_geometry, &tile_forced);
     const dim3 kgrid(cdiv(max_ns, tile_points));  // enough for the small tiles; on a sparse target the surplus blocks leave at once
     const int lb = (int)kgrid.x;  // one partial row per tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
@@ -1903,8 +1913,9 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
     static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
-    const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, hints, gp, thresh, grid_min, grid_rmax,
-                       cert_reach2, 0, 0, cert_off, recentre_keep, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env};
+    const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, guard_count, hints, gp, thresh, grid_min, grid_rmax,
+                       cert_reach2, 0, 0, cert_off, recentre_keep, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
+                       guard_min, (int)kgrid.x};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
@@ -2415,12 +2426,13 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
 int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                      const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
                      float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
-                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint) {
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint,
+                     const int32_t *guard_count, int guard_min) {
     const GradParams gp = grad_lm ? GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max),
                                                Bp, B2, (float)(1.0 / (double)nu)}
                                   : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f};
     return icp_run(grad_lm != 0, src, d_ns, max_ns, tgt, nrm, d_nt, max_nt, nullptr, numiters, damp, thresh, gp, hints, out_T, nullptr,
-                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out, dense_hint);
+                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out, dense_hint, guard_count, guard_min);
 }
 
 }  // namespace gs

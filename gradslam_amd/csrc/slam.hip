@@ -23,10 +23,11 @@ struct GraphKey {
     int B, capS, capT, numiters, use_grad;
     float damp, thresh, lmax, Bp, B2, nu;
     int dense, icp_cfg;  // what else decides WHICH kernels a loop launches: the density hint, gs_set_grid_search / _tile_points
+    const void *map_counts;  // the one caller-owned address a loop reads (the map's counts: LoopConst::guard_count, icp.hip)
     bool operator==(const GraphKey &o) const {
         return ws == o.ws && B == o.B && capS == o.capS && capT == o.capT && numiters == o.numiters && use_grad == o.use_grad &&
                damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu && dense == o.dense &&
-               icp_cfg == o.icp_cfg;
+               icp_cfg == o.icp_cfg && map_counts == o.map_counts;
     }
 };
 struct GraphEntry {
@@ -73,13 +74,15 @@ __global__ void compose_k(const float *__restrict__ T, const float *__restrict__
 int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                      const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
                      float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
-                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint);
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint,
+                     const int32_t *guard_count, int guard_min);
 int icp_config_stamp();  // icp.hip: the process-wide search / tiling switches, as one number
 // the ICP target holds about Nmax / ds^2 of the map's points: dense (several per ds-grid pixel) once the map has
 // seen a few frames -- what selects the grid search (icp.hip)
-static inline int target_dense(int Nmax, int H, int W, int ds) {
-    return (int64_t)Nmax >= 4LL * ds * ds * cdiv(H, ds) * cdiv(W, ds) ? 1 : 0;
+static inline int dense_map_points(int H, int W, int ds) {  // map size from which the target can hold 4 points per ds-grid pixel
+    return (int)std::min<int64_t>(4LL * ds * ds * cdiv(H, ds) * cdiv(W, ds), 0x7fffffff);
 }
+static inline int target_dense(int Nmax, int H, int W, int ds) { return Nmax >= dense_map_points(H, W, ds) ? 1 : 0; }
 
 __global__ void eye4_k(float *__restrict__ T, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +370,8 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     }
     // fold_compose: the loop's last launch also writes out_poses = T . prev_poses.  Only for eager launches: a
     // captured graph must not bake the caller's prev_poses / out_poses addresses in (they change every call).
+    // (map_counts IS baked in -- the loop's first launch reads the map's size from it -- and is part of the graph's key:
+    // a sequence driver keeps its counts in one device tensor for the whole sequence.)
     auto enqueue_loops = [&](gs_stream_t s, bool fold_compose) -> int {
         for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
             const float *src = w.src + (size_t)b * capS * 3;
@@ -377,7 +382,8 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
             const int r = icp_localize_run(use_grad_lm, src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, numiters, damp, dist_thresh,
                                            lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)s, nullptr,
                                            0, fold_compose ? prev_poses + 16 * b : nullptr,
-                                           fold_compose ? out_poses + 16 * b : nullptr, target_dense(Nmax, H, W, ds));
+                                           fold_compose ? out_poses + 16 * b : nullptr, target_dense(Nmax, H, W, ds),
+                                           map_counts + b, dense_map_points(H, W, ds));
             if (r) return r;
         }
         return GS_OK;
@@ -388,7 +394,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
         int device = 0;
         (void)hipGetDevice(&device);
         const GraphKey key{ws, B, capS, capT, numiters, use_grad_lm, damp, dist_thresh, lambda_max, Bp, B2, nu,
-                           target_dense(Nmax, H, W, ds), icp_config_stamp()};
+                           target_dense(Nmax, H, W, ds), icp_config_stamp(), map_counts};
         GraphEntry *hit = nullptr;
         for (auto &e : g_graphs)
             if (e.device == device && e.key == key) hit = &e;
@@ -658,7 +664,8 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
         if ((rc = icp_localize_run(use_grad_lm, tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
                                    w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, numiters, damp, dist_thresh, lambda_max, Bp, B2, nu,
                                    &hints, tp.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)stream, tp.icp + (size_t)b * tp.icp_bytes,
-                                   tp.icp_bytes, prev_poses + 16 * b, out_poses + 16 * b, target_dense(Nmax, H, W, ds))))
+                                   tp.icp_bytes, prev_poses + 16 * b, out_poses + 16 * b, target_dense(Nmax, H, W, ds),
+                                   map_counts + b, dense_map_points(H, W, ds))))
             return rc;
     }
     if (numiters == 0) return gs_compose_poses(tp.T, prev_poses, B, out_poses, stream);

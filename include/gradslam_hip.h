@@ -399,9 +399,9 @@ void gs_set_grid_search(int on);
 
 /* Source points per 1024-thread block of the loops' association kernel: 0 (default) = automatic -- 64, or
  * ceil(max_ns / 512) where max_ns lies between 16 385 and 32 768, search hints are given and the target holds at
- * least four points per ds-grid pixel (decided on the device from the target's count, so the choice is a function
- * of the data: every CU then hosts two equal tiles instead of some CUs two and most one); 32 .. 64 = that many,
- * whatever the density.  The tile size fixes the summation order of the 6x6 system, so results of different
+ * least four points per ds-grid pixel (decided on the device from the target's count -- inside gs_slam_localize
+ * also from the map's: at least 4 H W points -- so the choice is a function of the data: every CU then hosts two
+ * equal tiles instead of some CUs two and most one); 32 .. 64 = that many, whatever the density.  The tile size fixes the summation order of the 6x6 system, so results of different
  * settings agree to rounding, not bit for bit; nearest neighbours are the brute-force scan's under every setting.
  * Replaces nothing in the reference; for measurements and tests. */
 void gs_set_tile_points(int n);
