@@ -1913,7 +1913,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
     static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
-    const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, guard_count, hints, gp, thresh, grid_min, grid_rmax,
+    const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax,
                        cert_reach2, 0, 0, cert_off, recentre_keep, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
                        guard_min, (int)kgrid.x};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
