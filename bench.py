@@ -41,7 +41,7 @@ N_LIVE = 4  # distinct live frames cycled through (fresh RGBDImages each step: n
 
 
 def build_workload(gs, dev, seed):
-    from gradslam_amd.synthetic import make_sequence
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
     c, d, K, P = make_sequence(1, 1 + N_LIVE, H, W, seed=seed)
     c, d, K, P = c.to(dev), d.to(dev), K.to(dev), P.to(dev)
@@ -134,7 +134,7 @@ def hbm_roofline_linearize(gs, dev, n_pts=1 << 24, reps=20):
 def aux_pointfusion(gs, dev, raw, n_frames=30):
     """Auxiliary, NOT part of `value`: forward frames/s of the full PointFusion step (localise + map update,
     BASELINE configs[2] shape) over a short synthetic sequence, map growing from empty."""
-    from gradslam_amd.synthetic import make_sequence
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
     c, d, K, P = make_sequence(1, n_frames, H, W, seed=100)
     frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
@@ -182,7 +182,7 @@ def aux_association_sizes(gs, dev):
     """the association at ds = 1 (307 k x 307 k) and at the 1296x968 shape (ds = 4: 78 k x 78 k): one
     10-iteration LM loop, frame 1 against frame 0's cloud, timed with HIP events; ms per association = loop / 11."""
     from gradslam_amd import ops
-    from gradslam_amd.synthetic import make_sequence
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
     out = {}
     for tag, (h, w, ds) in (("640x480_ds1", (480, 640, 1)), ("1296x968_ds4", (968, 1296, 4))):
@@ -216,7 +216,7 @@ def aux_fusion_update_roofline(gs, dev, n_frames=31):
     frame by SURVEY 8(d)'s formula -- 12 N (projection) + 32 P (table) + 48 P (similar + unique) + 120 U (merge) +
     52 HW (maps) -- over the measured time of the call (HIP events), as a fraction of 8 TB/s."""
     from gradslam_amd import ops
-    from gradslam_amd.synthetic import make_sequence
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
     c, d, K, P = make_sequence(1, n_frames, H, W, seed=100)
     slam = gs.slam.PointFusion(odom="gt", dsratio=DS, numiters=ITERS, device=dev)
@@ -253,7 +253,7 @@ def aux_fusion_update_roofline(gs, dev, n_frames=31):
 def aux_c3_full_length(gs, dev, n_frames=200):
     """BASELINE configs[2] in full: PointFusion on 200 frames of 640x480, batch 1 -- forward (odom 'icp' and 'gradicp')
     and forward + backward (gradicp, the loss of the golden vectors)."""
-    from gradslam_amd.synthetic import make_sequence
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
     c, d, K, P = make_sequence(1, n_frames, H, W, seed=100)
     cd, dd, Kd, Pd = c.to(dev), d.to(dev), K.to(dev), P.to(dev)
@@ -335,7 +335,7 @@ def cpu_baseline(raw, n_frames=24):
                                        "times per frame"}
     # configs[2] on the CPU: PointFusion (localise + map update) over 10 frames
     L = 10
-    from gradslam_amd.synthetic import make_sequence
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
     c3, d3, K3, P3 = make_sequence(1, L, H, W, seed=100)
     t0 = time.perf_counter()

@@ -95,6 +95,7 @@ SIGNATURES = {
     "gs_set_grid_search": (None, [c_i]),
     "gs_set_tile_points": (None, [c_i]),
     "gs_icp_launch_geometry": (c_i, [c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
+    "gs_loop_counts": (c_i, [ctypes.POINTER(ctypes.c_uint), c_i]),
     "gs_profile_enable": (None, [c_i]),
     "gs_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),
     "gs_fusion_similar": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),

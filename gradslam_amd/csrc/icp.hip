@@ -211,6 +211,12 @@ struct KnnShared {
     } u;
 };
 
+// Counters (gs_loop_counts): what the DEVICE decided -- {loops prepared, loops whose association ran as a grid search
+// (variant launched AND the target's actual count dense enough), loops cut into small tiles, tiles whose point-serial
+// search overflowed its pair list and fell back to the tile-level search}.  One atomic per loop from icp_prepare_k (and
+// one per overflowing tile: a rare path); tests read them to make sure a run really exercised those paths.
+__device__ unsigned int g_loop_counts[4];
+
 #ifdef GS_DIAG_STAMPS
 // Diagnostic build only (libgradslam_hip_diag.so, never loaded by the product): per-wave phase stamps.
 __device__ unsigned long long *g_diag = nullptr;
@@ -512,8 +518,9 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
 // For one or two stragglers this costs a fraction of the tile-level search -- what a converging loop needs once nearly
 // every certificate holds.  Same contract as knn_prune_search<true>: sh.mm[point] receives the smallest bound /
 // distance met outside the point's window.  sh.cnt must be zero on entry (all waves past their last use of the
-// list's storage); ends with a barrier.
-__device__ __forceinline__ void knn_point_search(KnnShared &sh, const f3 s, const unsigned long long need_mask,
+// list's storage); ends with a barrier.  Returns false (block-uniform) when the pair list overflowed: nothing found is
+// final then and the caller must search again with knn_prune_search<true>.
+__device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, const unsigned long long need_mask,
                                                  const float *__restrict__ scan, const int32_t *__restrict__ scan_orig,
                                                  const float *__restrict__ boxes, const float *__restrict__ sboxes, const int nt,
                                                  const float tau /* look into every super-box nearer than this (squared) */) {
@@ -551,7 +558,16 @@ __device__ __forceinline__ void knn_point_search(KnnShared &sh, const f3 s, cons
         if (lane == 0) atomicMin(&sh.mm[L], fbits(mm));
     }
     __syncthreads();
-    const int npairs = min(sh.cnt, KNN_LIST);  // (6 points x 4096 super-boxes would be 64 M targets: never truncated)
+    // The list holds KNN_LIST (point, super-box) pairs IN TOTAL -- ~680 super-boxes (700 k targets) per point for six
+    // points.  A far-away straggler (huge bound: every super-box passes) on a large target overflows it; which pairs
+    // were dropped would depend on the atomics' arrival order, so nothing of this attempt is used: the caller runs the
+    // tile-level search for these points instead (block-uniform decision; sh.mm only ever holds valid lower bounds).
+    if (sh.cnt > KNN_LIST) {
+        if (threadIdx.x == 0) atomicAdd(&g_loop_counts[3], 1u);
+        __syncthreads();  // every wave has read sh.cnt before the caller's next search resets it
+        return false;
+    }
+    const int npairs = sh.cnt;
     for (int pi = wave; pi < npairs; pi += KNN_NW) {  // phase B
         const int pr = sh.u.a.list[pi];
         const int L = pr >> 24, sb = pr & 0xffffff;
@@ -605,6 +621,7 @@ __device__ __forceinline__ void knn_point_search(KnnShared &sh, const f3 s, cons
         if (lane == 0) atomicMin(&sh.mm[L], fbits(mm));
     }
     __syncthreads();
+    return true;
 }
 
 // returns the packed key of lane's point (KEY_NONE when there is no target)
@@ -1249,7 +1266,9 @@ struct LoopConst {
     int dense_min_per_pixel;  // ... dense = at least this many targets per ds-grid pixel on average (0: whatever the count)
     int guard_min;
     int loop_blocks;          // blocks of every association launch of this loop (the small tiles must cover the cloud)
+    int grid_variant;         // this loop launches knn1_loop_k<true> (for the loop counters only)
 };
+
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
                                                          const float *__restrict__ partials_in, int nblocks_in, int step_mode,
@@ -1419,7 +1438,9 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
 #pragma unroll
                         for (int q = 1; q < WBANDS; ++q) { bb = (rel + r) == q ? bbase[q] : bb; bn = (rel + r) == q ? bcnt[q] : bn; }
                         // inside the staged band, or not examined (then the lane has no certificate: `full`)
-                        if (lo >= bb && hi <= bb + bn) packed = LaneWin::pack(lo, hi - lo); else full = false;
+                        // (LaneWin packs the chunk count in 9 bits: a staged band is at most POOL / CHUNK = 256 chunks, but a
+                        // band read from memory has no such bound -- a longer row stays unpacked and the lane uncertified)
+                        if (lo >= bb && hi <= bb + bn && (hi - lo + CHUNK - 1) / CHUNK <= 511) packed = LaneWin::pack(lo, hi - lo); else full = false;
                     }
                 }
                 sh.win[r][lane] = packed;
@@ -1546,7 +1567,13 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
 #endif
         const unsigned long long need_mask = __ballot(need);  // the same 64 lanes in every wave: block-uniform
         GS_COUNT(12, (unsigned long long)__popcll(need_mask));
-        if (__popcll(need_mask) > 6) {
+        bool tile_search = __popcll(need_mask) > 6;
+        if (!tile_search && need_mask) {
+            tile_search = !knn_point_search(sh, s, need_mask, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt,
+                                            C->cert_reach2 * wave_max_f(ok ? bd : 0.0f));  // ends with a barrier
+            m_new = bitsf(sh.mm[lane]);
+        }
+        if (tile_search) {
             tile_box(sh, s, need);
             __syncthreads();
             knn_prune_search<true>(sh, s, ok, need, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt, C->cert_reach2);  // ends with a barrier
@@ -1561,10 +1588,6 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 GS_COUNT(15, n_tile | (um_t << 8) | (um_l << 32));
             }
 #endif
-        } else if (need_mask) {
-            knn_point_search(sh, s, need_mask, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt,
-                             C->cert_reach2 * wave_max_f(ok ? bd : 0.0f));  // ends with a barrier
-            m_new = bitsf(sh.mm[lane]);
         }
         GS_STAMP(2);
         key = ok ? sh.key[lane] : KEY_NONE;
@@ -1663,6 +1686,9 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
             const bool guard = lc.guard_count == nullptr || *lc.guard_count >= lc.guard_min;
             const bool covers = (int64_t)lc.loop_blocks * lc.tile_points >= (int64_t)*lc.d_ns;  // (by construction; never relied on)
             v = (dense && guard && covers) ? lc.tile_points : 64;
+            atomicAdd(&g_loop_counts[0], 1u);
+            if (v != 64) atomicAdd(&g_loop_counts[2], 1u);
+            if (lc.grid_variant && pixels > 0 && (int64_t)*lc.d_nt >= (int64_t)lc.grid_min_per_pixel * pixels) atomicAdd(&g_loop_counts[1], 1u);
         }
         reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
     }
@@ -1913,9 +1939,16 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
     static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
     static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
+    // all hints given: grid search with distance certificates (knn1_loop_k<true>); GS_NO_GRID_SEARCH=1 keeps the
+    // chunk-box search for every association (same results; for A/B measurements and tests)
+    static const bool grid_off = getenv("GS_NO_GRID_SEARCH") != nullptr;
+    // ... and only where the target can be dense enough for it (the kernel checks the actual count again): the grid
+    // variant carries more registers and 32 bytes of scratch, 1.4 us per launch on a sparse target
+    const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
+                             hints.grid_w > 0 && hints.grid_h > 0 && (g_grid_mode == 2 || dense);
     const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax,
                        cert_reach2, 0, 0, cert_off, recentre_keep, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
-                       guard_min, (int)kgrid.x};
+                       guard_min, (int)kgrid.x, grid_search ? 1 : 0};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
@@ -1930,13 +1963,6 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     // the kernel is throughput-bound and 4 us of redundant work in EVERY block costs more than one small launch:
     // then each step is a launch of its own again (measured at 78 k source points: 1225 blocks).
     const bool fold = (int)kgrid.x <= 2 * 256;
-    // all hints given: grid search with distance certificates (knn1_loop_k<true>); GS_NO_GRID_SEARCH=1 keeps the
-    // chunk-box search for every association (same results; for A/B measurements and tests)
-    static const bool grid_off = getenv("GS_NO_GRID_SEARCH") != nullptr;
-    // ... and only where the target can be dense enough for it (the kernel checks the actual count again): the grid
-    // variant carries more registers and 32 bytes of scratch, 1.4 us per launch on a sparse target
-    const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
-                             hints.grid_w > 0 && hints.grid_h > 0 && (g_grid_mode == 2 || dense);
     auto assoc = [&](int first) {
         if (!fold && pending >= 0) {  // stand-alone step, state updated in place
             hipLaunchKernelGGL(icp_step_k, dim3(1), dim3(1024), 0, st, w.S[cur], w.partials[cur], lb, pending, gp, trace, out_T,
@@ -2456,6 +2482,16 @@ int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_po
     if (blocks) *blocks = cdiv(max_ns, tp);
     if (tile_points_dense) *tile_points_dense = tp;
     if (partial_rows) *partial_rows = loop_blocks_max(max_ns);
+    return GS_OK;
+}
+
+int gs_loop_counts(unsigned int *out4, int reset) {
+    GS_REQUIRE(out4, "gs_loop_counts: NULL argument");
+    GS_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_loop_counts), 16), "gs_loop_counts");  // synchronises with the device
+    if (reset) {
+        const unsigned int z[4] = {0, 0, 0, 0};
+        GS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_loop_counts), z, 16), "gs_loop_counts/reset");
+    }
     return GS_OK;
 }
 

@@ -24,8 +24,9 @@ struct GraphKey {
     float damp, thresh, lmax, Bp, B2, nu;
     int dense, icp_cfg;  // what else decides WHICH kernels a loop launches: the density hint, gs_set_grid_search / _tile_points
     const void *map_counts;  // the one caller-owned address a loop reads (the map's counts: LoopConst::guard_count, icp.hip)
+    int H, W, ds;            // the loop's constants hold the ds-grid's dimensions and the map-size guard derived from them
     bool operator==(const GraphKey &o) const {
-        return ws == o.ws && B == o.B && capS == o.capS && capT == o.capT && numiters == o.numiters && use_grad == o.use_grad &&
+        return H == o.H && W == o.W && ds == o.ds && ws == o.ws && B == o.B && capS == o.capS && capT == o.capT && numiters == o.numiters && use_grad == o.use_grad &&
                damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu && dense == o.dense &&
                icp_cfg == o.icp_cfg && map_counts == o.map_counts;
     }
@@ -394,7 +395,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
         int device = 0;
         (void)hipGetDevice(&device);
         const GraphKey key{ws, B, capS, capT, numiters, use_grad_lm, damp, dist_thresh, lambda_max, Bp, B2, nu,
-                           target_dense(Nmax, H, W, ds), icp_config_stamp(), map_counts};
+                           target_dense(Nmax, H, W, ds), icp_config_stamp(), map_counts, H, W, ds};
         GraphEntry *hit = nullptr;
         for (auto &e : g_graphs)
             if (e.device == device && e.key == key) hit = &e;

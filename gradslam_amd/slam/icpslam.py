@@ -227,7 +227,11 @@ class ICPSLAM(nn.Module):
             recovered[:, s] = pose[:, 0]
             prev = pose
         pointclouds = arena.to_pointclouds()
-        for s, row in enumerate(stats.tolist()):  # the reference's warnings, raised once the sequence is done
+        rows = stats.tolist()
+        # diagnostics (no reference counterpart): rows appended per frame and sequence -- their running sum is the map size
+        # after every frame, which the long-sequence parity tests compare with the reference's
+        self.last_appended = [row[4:4 + B] for row in rows]
+        for s, row in enumerate(rows):  # the reference's warnings, raised once the sequence is done
             if row[2]:
                 raise RuntimeError("map arena overflow at frame {} (internal capacity bound violated)".format(s))
             self._stream_warnings(s, row)

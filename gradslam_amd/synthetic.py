@@ -16,7 +16,7 @@ requested size.  Colours are uniform random in [0,255).
 import numpy as np
 import torch
 
-__all__ = ["make_intrinsics", "make_poses", "make_sequence"]
+__all__ = ["make_intrinsics", "make_poses", "make_sequence", "make_sequence_cached"]
 
 
 def make_intrinsics(height: int, width: int) -> torch.Tensor:
@@ -79,3 +79,31 @@ def make_sequence(batch: int = 1, seq_len: int = 2, height: int = 480, width: in
         poses.append(P.astype(np.float32))
     return (torch.from_numpy(np.stack(colors)), torch.from_numpy(np.stack(depths)),
             K.repeat(batch, 1, 1, 1).contiguous(), torch.from_numpy(np.stack(poses)))
+
+
+def make_sequence_cached(batch: int = 1, seq_len: int = 2, height: int = 480, width: int = 640, seed: int = 0, **kw):
+    """make_sequence with the result kept under $GS_SYNTH_CACHE (default /tmp/gs_synth_cache): the fp64 ray cast of a
+    200-frame 640x480 sequence takes the better part of a minute on the host, and one GPU lease runs the same sequence
+    several times (bench, profiles, tests).  The cache holds this function's own output only."""
+    import hashlib
+    import os
+
+    root = os.environ.get("GS_SYNTH_CACHE", "/tmp/gs_synth_cache")
+    key = repr((batch, seq_len, height, width, seed, sorted(kw.items())))
+    path = os.path.join(root, "seq_" + hashlib.sha1(key.encode()).hexdigest()[:16] + ".pt")
+    if os.path.exists(path):
+        try:
+            out = torch.load(path, weights_only=True)
+            if isinstance(out, (list, tuple)) and len(out) == 4:
+                return tuple(out)
+        except Exception:
+            pass
+    out = make_sequence(batch, seq_len, height, width, seed, **kw)
+    try:
+        os.makedirs(root, exist_ok=True)
+        tmp = path + ".%d.tmp" % os.getpid()
+        torch.save(list(out), tmp)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return out

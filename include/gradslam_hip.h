@@ -409,6 +409,13 @@ void gs_set_tile_points(int n);
  * work): blocks launched, source points per block on a dense target, and the number of partial rows the workspace
  * (gs_icp_ws_bytes) holds per buffer (>= blocks for every tile-size setting). */
 int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_points_dense, int *partial_rows);
+/* What the DEVICE decided for the loops run so far (each loop's prepare kernel adds to four counters from the counts it
+ * finds on the device): out4 = {loops, loops associated by grid search (variant launched and the target's actual count
+ * at least four per ds-grid pixel), loops cut into small tiles, tiles whose point-serial straggler search overflowed
+ * its pair list and was redone by the tile-level search}.  Synchronises with the device; reset != 0 zeroes
+ * the counters afterwards.  Replaces nothing in the reference; lets a test assert that a long sequence really ran the
+ * dense-target paths. */
+int gs_loop_counts(unsigned int *out4, int reset);
 
 /* ---------------------------------------------------------------- C+U: fusion correspondences
  * find_similar_map_points (slam/fusionutils.py:381-401): keep[i] = |Vg(b,h,w) - p(b,n)| < dist_th

@@ -25,18 +25,24 @@ def _load():
         _lib = ctypes.CDLL(_SO)
         _lib.knn1_ref.restype = None
         _lib.knn1_ref_f64.restype = None
+        _lib.knn1_ref_wide.restype = None
     return _lib
 
 
-def knn1(src: torch.Tensor, tgt: torch.Tensor):
-    """src (Ns,3), tgt (Nt,3) fp32 CPU -> (dist2 (Ns,) fp32, idx (Ns,) int64)."""
+WIDE = False  # tests of long 640x480 sequences switch the sixteen-points-per-pass form on
+
+
+def knn1(src: torch.Tensor, tgt: torch.Tensor, wide=None):
+    """src (Ns,3), tgt (Nt,3) fp32 CPU -> (dist2 (Ns,) fp32, idx (Ns,) int64).
+    wide=True runs knn1_ref_wide (sixteen points per pass, bit-identical, ~10x faster); None = the module's WIDE."""
+    wide = WIDE if wide is None else wide
     lib = _load()
     s = np.ascontiguousarray(src.detach().cpu().numpy(), dtype=np.float32)
     t = np.ascontiguousarray(tgt.detach().cpu().numpy(), dtype=np.float32)
     d = np.empty(s.shape[0], dtype=np.float32)
     i = np.zeros(s.shape[0], dtype=np.int64)
     if s.shape[0] and t.shape[0]:
-        lib.knn1_ref(s.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(s.shape[0]),
+        (lib.knn1_ref_wide if wide else lib.knn1_ref)(s.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(s.shape[0]),
                      t.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(t.shape[0]),
                      d.ctypes.data_as(ctypes.c_void_p), i.ctypes.data_as(ctypes.c_void_p))
     return torch.from_numpy(d), torch.from_numpy(i)

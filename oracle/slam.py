@@ -21,7 +21,7 @@ def localize(cloud: Cloud, live: dict, prev: dict, odom: str, dsratio: int, **ic
 
 def run(rgb, depth, K, poses, *, mode: str = "pointfusion", odom: str = "gradicp", dsratio: int = 4,
         numiters: int = 20, damp: float = 1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0,
-        nu=200.0, dist_th=0.05, angle_th=20, sigma=0.6):
+        nu=200.0, dist_th=0.05, angle_th=20, sigma=0.6, counts_out=None):
     """rgb (B,L,H,W,3), depth (B,L,H,W,1), K (B,1,4,4), poses (B,L,4,4) or None ->
     (Cloud, recovered poses (B,L,4,4)).  reference slam/icpslam.py:99-178,
     slam/pointfusion.py:102-112."""
@@ -46,5 +46,7 @@ def run(rgb, depth, K, poses, *, mode: str = "pointfusion", odom: str = "gradicp
         else:
             cloud = update_map_aggregate(cloud, live)
         prev = live if odom != "gt" else None
+        if counts_out is not None:  # map size of the first sequence after every frame (long-sequence goldens)
+            counts_out.append(cloud.counts[0])
         out.append(pose[:, 0])
     return cloud, torch.stack(out, 1)

@@ -1356,3 +1356,147 @@ def test_grid_search_fuzz_against_bruteforce(gs, seed):
             assert int((keys != want).sum()) == 0, (seed, kw, mode, a)
         res[mode] = T.clone()
     assert torch.equal(res[2], res[0]), (seed, kw)
+
+
+# ------------------------------------------------------------------ round 3: the REFERENCE at the sizes the dense-target kernels run at
+def _loop_counts(gs, reset=False):
+    import ctypes
+
+    out = (ctypes.c_uint * 4)()
+    assert gs._native.lib().gs_loop_counts(out, 1 if reset else 0) == 0
+    return list(out)
+
+
+_C3_CACHE = {}
+
+
+def _c3_sequence(g):
+    from gradslam_amd.synthetic import make_sequence_cached as make_sequence
+
+    L, H, W, seed = (int(x) for x in g["shape"])
+    if "seq" not in _C3_CACHE:  # the ray-cast generator takes ~20 s for 64 frames: once per session
+        c, dd, K, P = make_sequence(1, L, H, W, seed=seed)
+        assert float(dd.double().sum()) == float(g["depths_sum"][0]) and float(c.double().sum()) == float(g["colors_sum"][0])
+        assert torch.equal(K, t(g["intrinsics"])) and torch.equal(P, t(g["poses_gt"]))
+        _C3_CACHE["seq"] = (c, dd, K, P)
+    return _C3_CACHE["seq"]
+
+
+@pytest.mark.parametrize("odom", ["icp", "gradicp"])
+def test_c3_64_frames_vs_reference(gs, golden, odom):
+    """BASELINE configs[2]'s shape against the REFERENCE itself (tests/golden/ref_slam_c3.npz, tools/gen_golden_c3.py:
+    the unmodified reference's PointFusion on 64 synthetic 640x480 frames, dsratio 4, 10 iterations): every recovered
+    pose to north_star's 1e-4 relative, the map size after EVERY frame, a strided sample of every attribute of the final
+    1.5 M-point map and fp64 checksums of the whole arrays -- under the default switches, with the device-side counters
+    proving that the grid search with certificates and the small tiles really ran (the target passes four points per
+    ds-grid pixel and the map 4 H W points on the way).  reference: slam/icpslam.py:99-138, slam/pointfusion.py:107-112."""
+    g = golden("ref_slam_c3")
+    c, dd, K, P = _c3_sequence(g)
+    L = c.shape[1]
+    _loop_counts(gs, reset=True)
+    slam = gs.slam.PointFusion(odom=odom, dsratio=4, numiters=10, device=DEV)
+    with torch.no_grad():
+        pcs, poses = slam(gs.RGBDImages(c.to(DEV), dd.to(DEV), K.to(DEV), P.to(DEV)))
+    loops, grid_loops, small_tile_loops, _ = _loop_counts(gs)
+    name = "pf_" + odom
+    ref_poses = t(g[name + "_poses"])
+    per_frame = (poses.cpu() - ref_poses).abs().amax((0, 2, 3)) / ref_poses.abs().amax((0, 2, 3))
+    err = rel_err(poses.cpu(), ref_poses)
+    counts = torch.tensor(slam.last_appended).sum(1).cumsum(0)
+    ref_counts = t(g[name + "_counts"])
+    dcount = (counts - ref_counts).abs()
+    print(name, "pose rel err", err, "worst frame", int(per_frame.argmax()), float(per_frame.max()), "| map size differs on",
+          int((dcount > 0).sum()), "of", L, "frames, by at most", int(dcount.max()), "of", int(ref_counts[-1]),
+          "| loops", loops, "grid", grid_loops, "small tiles", small_tile_loops)
+    assert loops == L - 1 and grid_loops >= 20 and small_tile_loops >= 10, (loops, grid_loops, small_tile_loops)
+    assert err < 1e-4, (name, err)
+    # map sizes: a point is appended iff its pixel found no correspondence -- a threshold on fp32 distances / dot products,
+    # so a handful of the 300 k decisions per frame may flip where a 1-ulp difference of a pose meets a threshold
+    assert int(dcount.max()) <= max(4, int(ref_counts[-1]) // 100000), (name, dcount.max())
+    n, st = int(pcs.num_points_per_pointcloud.item()), int(g["stride"][0])
+    if n == int(ref_counts[-1]) and int((dcount > 0).sum()) == 0:
+        for attr, key in (("points_list", "points"), ("normals_list", "normals"), ("colors_list", "colors"), ("features_list", "feats")):
+            a = getattr(pcs, attr)[0].cpu()
+            ref = t(g[f"{name}_map_{key}"])
+            bad = ((a[::st].double() - ref.double()).abs().amax(1) > 1e-4 * ref.abs().max()).float().mean().item()
+            s_ref = g[f"{name}_map_{key}_sum"]
+            s_err = abs(float(a.double().abs().sum()) - s_ref[1]) / s_ref[1]
+            print("   ", key, "sampled rows off by > 1e-4:", bad, "| checksum rel err", s_err)
+            assert bad < 1e-3 and s_err < 1e-5, (name, key, bad, s_err)
+
+
+FIXTURE_CASES = [("pf_icp", "PointFusion", "icp"), ("pf_gradicp", "PointFusion", "gradicp"),
+                 ("is_icp", "ICPSLAM", "icp"), ("is_gradicp", "ICPSLAM", "gradicp")]
+
+
+@pytest.mark.parametrize("name,cls,odom", FIXTURE_CASES)
+def test_fixture_full_slam_vs_reference(gs, golden, name, cls, odom):
+    """Full SLAM on the reference's own REAL-SENSOR fixture (tests/data/msrd_b2s3: B = 2, L = 3, 160x120, 11.8 % holes,
+    fy < 0) against the reference's outputs (tests/golden/ref_slam_fixture.npz, tools/gen_golden_fixture.py): poses,
+    per-sequence map sizes, map attributes (strided sample + checksums) from the no-grad path, then the four input
+    gradients of  poses.sum() + points.sum() + colors.mean()  against the reference's autograd.
+    reference: slam/icpslam.py:99-138, slam/pointfusion.py:107-112."""
+    fx, g = golden("msrd_b2s3"), golden("ref_slam_fixture")
+    inputs = [t(fx[k]) for k in ("colors", "depths", "intrinsics", "poses")]
+    slam = getattr(gs.slam, cls)(odom=odom, dsratio=4, numiters=10, device=DEV)
+    with torch.no_grad():
+        pcs, poses = slam(gs.RGBDImages(*[x.to(DEV) for x in inputs]))
+    err = rel_err(poses.cpu(), g[name + "_poses"])
+    print(name, "pose rel err", err, "maps", pcs.num_points_per_pointcloud.tolist(), "reference", g[name + "_counts"].tolist())
+    assert err < 1e-4, (name, err)
+    st = int(g[name + "_map_stride"][0])
+
+    def check_map(pcs):
+        assert pcs.num_points_per_pointcloud.tolist() == g[name + "_counts"].tolist()
+        attrs = [("points_list", "points"), ("normals_list", "normals"), ("colors_list", "colors")]
+        if cls == "PointFusion":
+            attrs.append(("features_list", "feats"))
+        for b in range(2):
+            for attr, key in attrs:
+                a = getattr(pcs, attr)[b].detach().cpu()
+                e = rel_err(a[::st], g[f"{name}_map_{key}_{b}"])
+                s_ref = g[f"{name}_map_{key}_{b}_sum"]
+                s_err = abs(float(a.double().abs().sum()) - s_ref[1]) / s_ref[1]
+                assert e < 1e-4 and s_err < 1e-5, (name, b, key, e, s_err)
+
+    check_map(pcs)
+    c, dd, K, P = (x.to(DEV).clone().requires_grad_(True) for x in inputs)
+    pcs, poses = slam(gs.RGBDImages(c, dd, K, P))
+    (poses.sum() + pcs.points_padded.sum() + pcs.colors_padded.mean()).backward()
+    assert rel_err(poses.detach().cpu(), g[name + "_poses"]) < 1e-4
+    check_map(pcs)
+    cs = int(g["color_grad_stride"][0])
+    e_c = rel_err(c.grad.cpu().reshape(-1, 3)[::cs], g[name + "_grad_colors"])
+    e_p = rel_err(P.grad.cpu(), g[name + "_grad_poses"])
+    ref = t(g[name + "_grad_depths"]).double()
+    off = ((dd.grad.cpu().double() - ref).abs() > 1e-3 * ref.abs().max()).sum().item()
+    e_k = rel_err(K.grad.cpu(), g[name + "_grad_intrinsics"])
+    print(name, "gradients: colours", e_c, "poses", e_p, "intrinsics", e_k, "depth pixels off by > 1e-3 of the maximum:", off)
+    assert e_c < 1e-4 and e_p < 1e-3 and e_k < 5e-3 and off <= 16, (name, e_c, e_p, e_k, off)
+
+
+def test_straggler_search_overflow_falls_back_to_the_tile_search(gs):
+    """the point-serial search for up to six uncertified lanes of a tile shares ONE 4096-entry list
+    of (point, super-box) pairs.  One far-away lane makes the common look-ahead radius huge, every super-box then passes
+    for every straggler, and on a target of more than ~700 k points six stragglers overflow the list -- the pairs that
+    were dropped used to depend on the atomics' arrival order.  Now the attempt is discarded and the tile-level search
+    runs.  768 k targets, six far outliers in each of 40 tiles: every association must still be the brute-force scan's,
+    and the device-side counter must show that the fallback ran."""
+    sc = _grid_scene(seed=5, Hd=240, Wd=320, per_cell=20, motion=0.0005)
+    src = sc["src"].clone()
+    for tile in range(20, 1000, 25):
+        src[64 * tile + 10: 64 * tile + 16, 2] += 4.0
+    sc["src"] = src.contiguous()
+    lib = gs._native.lib()
+    _loop_counts(gs, reset=True)
+    lib.gs_set_grid_search(2)
+    try:
+        T, assoc = _taped_loop_with_hints(gs, sc, 4, 0)
+    finally:
+        lib.gs_set_grid_search(1)
+    overflows = _loop_counts(gs)[3]
+    print("targets", sc["tgt"].shape[0], "sources", sc["src"].shape[0], "overflowing tile searches", overflows)
+    for a, (cloud, keys) in enumerate(assoc):
+        want = gs.ops.knn1_raw(cloud.contiguous(), sc["tgt"], brute_force=True)
+        assert (keys != want).sum().item() == 0, a
+    assert sc["tgt"].shape[0] > 700000 and overflows > 0

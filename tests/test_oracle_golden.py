@@ -217,3 +217,77 @@ def test_config1b_slam_and_gradients(golden, name, mode, odom):
             assert ((got - ref).abs() > 1e-3 * ref.abs().max()).sum().item() <= 16
         else:
             assert rel_err(got, ref) < 5e-3, (k, rel_err(got, ref))
+
+
+# ------------------------------------------------------------------ full SLAM on the reference's real-sensor fixture
+FIXTURE_CASES = [("pf_icp", "pointfusion", "icp"), ("pf_gradicp", "pointfusion", "gradicp"),
+                 ("is_icp", "icpslam", "icp"), ("is_gradicp", "icpslam", "gradicp")]
+
+
+@pytest.mark.parametrize("name,mode,odom", FIXTURE_CASES)
+def test_fixture_slam_and_gradients(golden, name, mode, odom):
+    """tools/gen_golden_fixture.py: the reference's msrd_b2s3 fixture (B = 2, L = 3, 160x120, holes, fy < 0) through its
+    ICPSLAM / PointFusion forward (slam/icpslam.py:99-138) -- the oracle against the reference's poses, per-sequence
+    map sizes, map attributes (strided sample + checksums of the whole arrays) and its autograd's input gradients."""
+    fx, g = golden("msrd_b2s3"), golden("ref_slam_fixture")
+    c, d, K, P = (t(fx[k]).clone().requires_grad_(True) for k in ("colors", "depths", "intrinsics", "poses"))
+    cloud, poses = slam.run(c, d, K, P, mode=mode, odom=odom, dsratio=4, numiters=10)
+    assert rel_err(poses.detach(), g[name + "_poses"]) < 1e-5
+    assert cloud.counts == g[name + "_counts"].tolist()
+    st = int(g[name + "_map_stride"][0])
+    attrs = ["points", "normals", "colors"] + (["feats"] if mode == "pointfusion" else [])
+    for b in range(2):
+        for attr in attrs:
+            a = getattr(cloud, attr)[b].detach()
+            assert rel_err(a[::st], g[f"{name}_map_{attr}_{b}"]) < 1e-5, (b, attr)
+            s_ref = g[f"{name}_map_{attr}_{b}_sum"]
+            assert abs(float(a.double().abs().sum()) - s_ref[1]) <= 1e-6 * s_ref[1], (b, attr)
+    (poses.sum() + cloud.padded("points").sum() + cloud.padded("colors").mean()).backward()
+    cs = int(g["color_grad_stride"][0])
+    assert rel_err(c.grad.reshape(-1, 3)[::cs], g[name + "_grad_colors"]) < 1e-4
+    assert rel_err(P.grad, g[name + "_grad_poses"]) < 1e-3
+    ref = t(g[name + "_grad_depths"]).double()
+    off = ((d.grad.double() - ref).abs() > 1e-3 * ref.abs().max()).sum().item()
+    print(name, "depth-gradient pixels off by > 1e-3 of the maximum:", off, "intrinsics",
+          rel_err(K.grad, g[name + "_grad_intrinsics"]), "poses", rel_err(P.grad, g[name + "_grad_poses"]))
+    assert off <= 16
+    assert rel_err(K.grad, g[name + "_grad_intrinsics"]) < 5e-3
+
+
+def test_wide_search_is_the_serial_search():
+    """oracle/knn_ref.c: knn1_ref_wide (sixteen points per pass; used by the 640x480 golden generator's stand-in and the
+    long-sequence tests) returns the bits of knn1_ref -- ties (lattice), ragged sizes, more targets than sources."""
+    from oracle import knn
+
+    gen = torch.Generator().manual_seed(3)
+    for ns, nt, lattice in ((1, 1, False), (17, 5, True), (1000, 3333, True), (2500, 9000, False)):
+        s = torch.rand(ns, 3, generator=gen)
+        tg = torch.rand(nt, 3, generator=gen)
+        if lattice:
+            s, tg = (s * 8).round() / 8, (tg * 8).round() / 8
+        d0, i0 = knn.knn1(s, tg, wide=False)
+        d1, i1 = knn.knn1(s, tg, wide=True)
+        assert torch.equal(d0, d1) and torch.equal(i0, i1)
+
+
+# ------------------------------------------------------------------ BASELINE configs[2]'s shape, first frames (CPU)
+@pytest.mark.parametrize("odom", ["icp", "gradicp"])
+def test_c3_first_frames_vs_reference(golden, odom):
+    """tools/gen_golden_c3.py: the reference's PointFusion on 64 synthetic 640x480 frames.  The oracle replays the first
+    six here (the GPU tests replay all 64 on the HIP path): poses to 1e-5, the map size after every frame exactly."""
+    from gradslam_amd.synthetic import make_sequence
+    from oracle import knn
+
+    g = golden("ref_slam_c3")
+    L, H, W, seed = (int(x) for x in g["shape"])
+    n = 6
+    c, d, K, P = make_sequence(1, n, H, W, seed=seed)
+    knn.WIDE = True
+    try:
+        counts = []
+        cloud, poses = slam.run(c, d, K, P, mode="pointfusion", odom=odom, dsratio=4, numiters=10, counts_out=counts)
+    finally:
+        knn.WIDE = False
+    assert torch.equal(P, t(g["poses_gt"])[:, :n])
+    assert rel_err(poses, g[f"pf_{odom}_poses"][:, :n]) < 1e-5
+    assert counts == g[f"pf_{odom}_counts"][:n].tolist()

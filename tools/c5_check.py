@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gradslam_amd as gs
-from gradslam_amd.synthetic import make_sequence
+from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 dev = "cuda:0"
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 c, d, K, P = make_sequence(1, L, 968, 1296, seed=11)

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gradslam_amd as gs
 from gradslam_amd import _native
-from gradslam_amd.synthetic import make_sequence
+from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 dev = "cuda:0"

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from gradslam_amd import _native
 _native.LIB_PATH = os.path.join(ROOT, "gradslam_amd", "libgradslam_hip_diag.so")
 import gradslam_amd as gs
-from gradslam_amd.synthetic import make_sequence
+from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 numiters = int(sys.argv[2]) if len(sys.argv) > 2 else 10  # < 10: the LAST frame only is cut short, so the last launch is association numiters + 1

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gradslam_amd as gs
-from gradslam_amd.synthetic import make_sequence
+from gradslam_amd.synthetic import make_sequence_cached as make_sequence
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 odom = sys.argv[2] if len(sys.argv) > 2 else "icp"
