@@ -136,7 +136,7 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.gs_abi_version() != 2:
+        if handle.gs_abi_version() != 3:
             raise RuntimeError("gradslam_amd: ABI version mismatch")
         _lib = handle
     return _lib

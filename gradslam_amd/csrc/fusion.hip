@@ -4,9 +4,12 @@
 // All HBM/L2-bound gathers keyed by the [b,n,h,w] table.  U replaces the reference's lexicographic
 // row sort (torch.unique(dim=0) over P x 6 floats, ~90 % of its mapping time) by two per-pixel atomic
 // min passes on order-preserving integer keys followed by a stable compaction over pixels, which
-// yields the identical winners in the identical (b,h,w) output order.
+// yields the identical winners in the identical (b,h,w) output order.  The stand-alone entry points keep
+// the reference's tables; gs_pointfusion_update runs the same tests as ONE table-free chain over the map
+// points (corr_pass1_k / corr_pass2_k / merge_corr_k below).
 #include "gs_common.hpp"
 #include "gs_compact.hpp"
+#include "gs_project.hpp"
 
 namespace gs {
 
@@ -92,24 +95,6 @@ struct PixWriter {
     }
 };
 
-// PixWriter that also records, per matched map point, the pixel it matched (what scatter_match_k builds for the
-// merge): the arena driver's fused form
-struct PixWriterM {
-    const unsigned int *pix_n;
-    int64_t *rows;
-    int *match;  // (B*Nmax), pre-filled with -1
-    int H, W, Nmax;
-    __device__ void operator()(int64_t i, int64_t pos) const {
-        const int64_t hw = (int64_t)H * W;
-        const int b = (int)(i / hw);
-        const int rem = (int)(i - (int64_t)b * hw);
-        const unsigned int n = pix_n[i];
-        longlong4 r;
-        r.x = b; r.y = n; r.z = rem / W; r.w = rem % W;
-        *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
-        match[(int64_t)b * Nmax + n] = rem;
-    }
-};
 // fuse_with_map's append mask (slam/fusionutils.py:702-707) straight from the unique stage's per-pixel winner:
 // valid depth and no correspondence at that pixel
 struct AppendPredPix {
@@ -443,66 +428,258 @@ int gs_fusion_merge(const int64_t *rows, const int32_t *d_n_rows, int64_t max_ro
 }  // extern "C"
 
 namespace gs {
-// ---- fused forms used by gs_pointfusion_update (slam.hip): same kernels, fewer launches.
-// state = [pix_key (npix x 8) | pix_n (npix x 4) | match (B*Nmax x 4)], all initialised by ONE memset (0xff:
-// "no candidate" for the keys, "no winner" for pix_n, -1 for match); pix_n and match stay valid for the
-// merge and the append that follow.
-size_t fusion_state_bytes(int B, int H, int W, int Nmax) {
-    const size_t npix = (size_t)B * H * W;
-    return align_up(npix * 8, 256) + align_up(npix * 4, 256) + align_up((size_t)B * Nmax * 4, 256);
-}
-static inline void fusion_state_ptrs(void *state, int B, int H, int W, unsigned long long **key, unsigned int **pix_n, int **match) {
-    const size_t npix = (size_t)B * H * W;
-    *key = (unsigned long long *)state;
-    *pix_n = (unsigned int *)((char *)state + align_up(npix * 8, 256));
-    *match = (int *)((char *)*pix_n + align_up(npix * 4, 256));
-}
-int fusion_unique_match(const int64_t *rows, const uint8_t *keep, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
-                        int B, int H, int W, const float *map_points, const float *map_ccounts, int Nmax, int64_t *out_rows,
-                        int32_t *out_count, void *state, void *cws, hipStream_t st) {
-    unsigned long long *pix_key; unsigned int *pix_n; int *match;
-    fusion_state_ptrs(state, B, H, W, &pix_key, &pix_n, &match);
-    GS_HIP(hipMemsetAsync(state, 0xff, fusion_state_bytes(B, H, W, Nmax), st), "gs_pointfusion_update/unique memset");
-    if (max_rows > 0) {
-        hipLaunchKernelGGL(unique_pass1_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, keep, d_n_rows, gvertex, H, W, map_points,
-                           map_ccounts, Nmax, pix_key);
-        hipLaunchKernelGGL(unique_pass2_k, dim3(grid1d(max_rows)), dim3(256), 0, st, rows, keep, d_n_rows, gvertex, H, W, map_points,
-                           map_ccounts, Nmax, pix_key, pix_n);
-        GS_LAUNCH_CHECK("gs_pointfusion_update/unique");
+// ------------------------------------------------------------------ fused correspondence chain (gs_pointfusion_update)
+// find_correspondences (slam/fusionutils.py:549-577 = :247-282 + :381-401 + :489-546) without its tables.  The reference
+// materialises the (P,4) table of active rows, filters it into the similar rows, and sorts those to keep one per pixel.
+// Inside the update none of the three tables is an output, so ONE pass over the map does, per map point: transform +
+// project + in-frame test (project_point: the very function the table-building entry point uses), gather of the frame's
+// global vertex / normal at the pixel, distance and angle tests (similar_k's arithmetic), and -- for a similar point -- the
+// 64-bit atomicMin of its (1 / (c + 1e-20), squared ray distance) key on the pixel (unique_pass1_k's).  What it leaves
+// behind is 4 bytes per map point: the pixel it competes for, or -1.  Pass 2 (ties between equal keys go to the
+// smallest point index, like the reference's row sort) and the merge read that word instead of 32-byte rows.
+constexpr int CORR_T = 256, CORR_I = 4, CORR_B = CORR_T * CORR_I;
+constexpr int FLAG_ANY = 4;  // word of the counter block: 1 if any similar point was found (the merge runs only then); pass 2's first block sets it
+
+__global__ __launch_bounds__(CORR_T) void corr_pass1_k(const float *__restrict__ mp, const float *__restrict__ mn,
+                                                       const float *__restrict__ cc, const int32_t *__restrict__ counts, int Nmax,
+                                                       const float *__restrict__ poses, const float *__restrict__ Ks, int H, int W,
+                                                       float umax, float vmax, const float *__restrict__ gv,
+                                                       const float *__restrict__ gn, float dist_th, float dot_th,
+                                                       unsigned long long *__restrict__ pix_key, int *__restrict__ pt_pix,
+                                                       int32_t *__restrict__ part_active, int32_t *__restrict__ part_similar,
+                                                       int32_t *__restrict__ ctr) {
+    __shared__ Cam cam;
+    __shared__ int red[2][CORR_T / 64];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) cam = make_cam(poses + 16 * b, Ks + 16 * b);
+    __syncthreads();
+    const int cnt = min(counts[b], Nmax);
+    const int64_t HW = (int64_t)H * W;
+    int n_act = 0, n_sim = 0;
+    float md = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CORR_I; ++k) {
+        const int n = blockIdx.x * CORR_B + k * CORR_T + threadIdx.x;
+        if (n >= cnt) continue;
+        const int64_t pt = (int64_t)b * Nmax + n;
+        const f3 p = ld3(mp, pt);
+        int h, w, out = -1;
+        if (project_point(cam, p, H, W, umax, vmax, h, w)) {
+            ++n_act;
+            const int px = h * W + w;
+            const int64_t pix = b * HW + px;
+            const f3 fv = ld3(gv, pix), fn = ld3(gn, pix), q = ld3(mn, pt);
+            const float dx = fv.x - p.x, dy = fv.y - p.y, dz = fv.z - p.z;
+            // (a-b).norm(dim=-1): sqrt(fma(z,z,fma(y,y,x*x)));  (a*b).sum(-1): unfused      (similar_k)
+            const float dist = sqrtf(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)));
+            const float dot = (fn.x * q.x + fn.y * q.y) + fn.z * q.z;
+            md = fmaxf(md, dot);
+            if (dist < dist_th && dot > dot_th) {
+                out = px;
+                ++n_sim;
+                atomicMin(pix_key + pix, unique_key(gv, mp, cc, pix, pt));
+            }
+        }
+        pt_pix[pt] = out;
     }
-    PixPred pred{pix_n};
-    PixWriterM wr{pix_n, out_rows, match, H, W, Nmax};
-    return compact_launch((int64_t)B * H * W, pred, wr, out_count, cws, st, "gs_pointfusion_update/unique compact");
+    n_act = wave_sum_i(n_act);
+    n_sim = wave_sum_i(n_sim);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) md = fmaxf(md, __shfl_xor(md, off, kWave));
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = n_act;
+        red[1][threadIdx.x >> 6] = n_sim;
+        // the caller only warns when a dot product exceeds 1.001 (un-normalised normals): publish the maximum only when
+        // it is above 1, so that the usual case costs no same-address atomics (similar_k)
+        if (md > 1.0f) atomicMax(ctr + 3, __float_as_int(md));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {  // per-block counts, summed by later launches: no same-address traffic from 25 k waves
+        int sum = 0;
+        for (int wv = 0; wv < CORR_T / 64; ++wv) sum += red[threadIdx.x][wv];
+        (threadIdx.x == 0 ? part_active : part_similar)[blockIdx.y * gridDim.x + blockIdx.x] = sum;
+    }
 }
-int fusion_merge_prebuilt(const void *state, const int32_t *d_n_rows, const float *gvertex, const float *gnormal, const float *rgb,
-                          const float *alpha, int B, int H, int W, int Nmax, const int32_t *counts, float *points, float *normals,
-                          float *colors, float *ccounts, hipStream_t st) {
-    unsigned long long *pix_key; unsigned int *pix_n; int *match;
-    fusion_state_ptrs((void *)state, B, H, W, &pix_key, &pix_n, &match);
-    hipLaunchKernelGGL(merge_inplace_k, dim3(grid1d(Nmax), B), dim3(256), 0, st, (const int *)match, counts, d_n_rows, Nmax, H * W,
-                       gvertex, gnormal, rgb, alpha, points, normals, colors, ccounts);
+
+// among the similar points whose key IS the pixel's minimum, the smallest point index wins (unique_pass2_k)
+__global__ __launch_bounds__(CORR_T) void corr_pass2_k(const int *__restrict__ pt_pix, const int32_t *__restrict__ counts, int Nmax,
+                                                       int64_t HW, const float *__restrict__ gv, const float *__restrict__ mp,
+                                                       const float *__restrict__ cc, const unsigned long long *__restrict__ pix_key,
+                                                       unsigned int *__restrict__ pix_n, const int32_t *__restrict__ part_similar,
+                                                       int nparts, int32_t *__restrict__ ctr) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // "any similar point at all?" for the merge (the launch after this one)
+        int any = 0;
+        for (int i = threadIdx.x; i < nparts; i += CORR_T) any |= part_similar[i];
+        if (__any(any != 0) && (threadIdx.x & 63) == 0) ctr[FLAG_ANY] = 1;
+    }
+    const int b = blockIdx.y;
+    const int cnt = min(counts[b], Nmax);
+#pragma unroll
+    for (int k = 0; k < CORR_I; ++k) {
+        const int n = blockIdx.x * CORR_B + k * CORR_T + threadIdx.x;
+        if (n >= cnt) continue;
+        const int64_t pt = (int64_t)b * Nmax + n;
+        const int px = pt_pix[pt];
+        if (px < 0) continue;
+        const int64_t pix = b * HW + px;
+        if (unique_key(gv, mp, cc, pix, pt) == pix_key[pix]) atomicMin(pix_n + pix, (unsigned int)n);
+    }
+}
+
+// merge_inplace_k with the match read from (pt_pix, pix_n): point n merges with its pixel iff it is that pixel's winner.
+// Also counts the winners (= unique correspondences) per block, for the update's statistics.
+__global__ __launch_bounds__(CORR_T) void merge_corr_k(const int *__restrict__ pt_pix, const unsigned int *__restrict__ pix_n,
+                                                       const int32_t *__restrict__ counts, const int32_t *__restrict__ ctr, int Nmax,
+                                                       int HW, const float *__restrict__ gv, const float *__restrict__ gn,
+                                                       const float *__restrict__ rgb, const float *__restrict__ alpha, float *p,
+                                                       float *nn, float *cl, float *cc, int32_t *__restrict__ part_u) {
+    __shared__ int red[CORR_T / 64];
+    int n_u = 0;
+    if (ctr[FLAG_ANY] != 0) {  // no correspondence at all: fuse_with_map skips the merge (fusionutils.py:654)
+        const int b = blockIdx.y;
+        const int cnt = min(counts[b], Nmax);
+#pragma unroll
+        for (int k = 0; k < CORR_I; ++k) {
+            const int n = blockIdx.x * CORR_B + k * CORR_T + threadIdx.x;
+            if (n >= cnt) continue;
+            const int64_t pt = (int64_t)b * Nmax + n;
+            const int px = pt_pix[pt];
+            float a = 0.0f;
+            f3 fp{0, 0, 0}, fn{0, 0, 0}, fc{0, 0, 0};
+            if (px >= 0) {
+                const int64_t pix = (int64_t)b * HW + px;
+                if (pix_n[pix] == (unsigned int)n) {
+                    ++n_u;
+                    a = alpha[pix]; fp = ld3(gv, pix); fn = ld3(gn, pix); fc = ld3(rgb, pix);
+                }
+            }
+            const float c = cc[pt];
+            const float c2 = c + a;
+            const float inv = 1.0f / (c2 == 0.0f ? 1.0f : c2);
+            const f3 x = ld3(p, pt), y = ld3(nn, pt), z = ld3(cl, pt);
+            st3(p, pt, f3{((c * x.x) + (a * fp.x)) * inv, ((c * x.y) + (a * fp.y)) * inv, ((c * x.z) + (a * fp.z)) * inv});
+            st3(nn, pt, f3{((c * y.x) + (a * fn.x)) * inv, ((c * y.y) + (a * fn.y)) * inv, ((c * y.z) + (a * fn.z)) * inv});
+            st3(cl, pt, f3{((c * z.x) + (a * fc.x)) * inv, ((c * z.y) + (a * fc.y)) * inv, ((c * z.z) + (a * fc.z)) * inv});
+            cc[pt] = c2;
+        }
+    }
+    n_u = wave_sum_i(n_u);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n_u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int wv = 0; wv < CORR_T / 64; ++wv) sum += red[wv];
+        part_u[blockIdx.y * gridDim.x + blockIdx.x] = sum;
+    }
+}
+
+// the update's last launch: the per-block counts of the two passes summed (fixed order), every sequence's row count
+// advanced by what its append pass selected (append_count_k for all b at once), the statistics row written
+__global__ __launch_bounds__(1024) void fuse_finish_k(const int32_t *__restrict__ part_active, const int32_t *__restrict__ part_u,
+                                                      int nparts, int32_t *__restrict__ ctr, int32_t *__restrict__ counts,
+                                                      const int *__restrict__ totals, int B, int cap, int32_t *__restrict__ appended,
+                                                      int32_t *__restrict__ stats) {
+    __shared__ int red[2][16];
+    int a = 0, u = 0;
+    for (int i = threadIdx.x; i < nparts; i += 1024) { a += part_active[i]; u += part_u[i]; }
+    a = wave_sum_i(a); u = wave_sum_i(u);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = u; }
+    if ((int)threadIdx.x < B) {
+        const int64_t want = (int64_t)counts[threadIdx.x] + totals[threadIdx.x];
+        const int now = (int)(want > cap ? cap : want);
+        appended[threadIdx.x] = now - counts[threadIdx.x];
+        if (want > cap) ctr[2] = 1;
+        counts[threadIdx.x] = now;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sa = 0, su = 0;
+        for (int wv = 0; wv < 16; ++wv) { sa += red[0][wv]; su += red[1][wv]; }
+        ctr[0] = sa; ctr[1] = su;
+        if (stats) { stats[0] = sa; stats[1] = su; stats[2] = ctr[2]; stats[3] = ctr[3]; }
+    }
+    if (stats && (int)threadIdx.x < B) stats[4 + threadIdx.x] = appended[threadIdx.x];
+}
+
+// ---- the fused chain's host side (slam.hip drives it).  state = [pix_key (npix x 8) | pix_n (npix x 4) | pt_pix
+// (B*Nmax x 4) | part_active, part_u (blocks x 4 each)]; pix_key / pix_n are initialised by the maps kernel (VnExtra).
+static inline int corr_blocks(int Nmax) { return cdiv(Nmax > 0 ? Nmax : 1, CORR_B); }
+size_t fusion_corr_state_bytes(int B, int H, int W, int Nmax) {
+    const size_t npix = (size_t)B * H * W;
+    return align_up(npix * 8, 256) + align_up(npix * 4, 256) + align_up((size_t)B * Nmax * 4, 256) +
+           3 * align_up((size_t)B * corr_blocks(Nmax) * 4, 256);
+}
+struct CorrState {
+    unsigned long long *pix_key;
+    unsigned int *pix_n;
+    int *pt_pix;
+    int32_t *part_active, *part_similar, *part_u;
+};
+static inline CorrState corr_state_ptrs(void *state, int B, int H, int W, int Nmax) {
+    const size_t npix = (size_t)B * H * W;
+    char *p = (char *)state;
+    CorrState c;
+    c.pix_key = (unsigned long long *)p; p += align_up(npix * 8, 256);
+    c.pix_n = (unsigned int *)p; p += align_up(npix * 4, 256);
+    c.pt_pix = (int *)p; p += align_up((size_t)B * Nmax * 4, 256);
+    c.part_active = (int32_t *)p; p += align_up((size_t)B * corr_blocks(Nmax) * 4, 256);
+    c.part_similar = (int32_t *)p; p += align_up((size_t)B * corr_blocks(Nmax) * 4, 256);
+    c.part_u = (int32_t *)p;
+    return c;
+}
+void fusion_corr_init_ptrs(void *state, int B, int H, int W, int Nmax, unsigned long long **pix_key, unsigned int **pix_n) {
+    const CorrState c = corr_state_ptrs(state, B, H, W, Nmax);
+    *pix_key = c.pix_key; *pix_n = c.pix_n;
+}
+// passes 1 and 2: afterwards pix_n holds every pixel's winner (or ~0) and pt_pix every map point's pixel (or -1)
+int fusion_correspond(void *state, const float *map_points, const float *map_normals, const float *map_ccounts, const int32_t *counts,
+                      int B, int Nmax, const float *poses, const float *intrinsics, int H, int W, const float *gvertex,
+                      const float *gnormal, float dist_th, float dot_th, int32_t *ctr, hipStream_t st) {
+    const CorrState c = corr_state_ptrs(state, B, H, W, Nmax);
+    const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
+    const dim3 grid(corr_blocks(Nmax), B);
+    hipLaunchKernelGGL(corr_pass1_k, grid, dim3(CORR_T), 0, st, map_points, map_normals, map_ccounts, counts, Nmax, poses, intrinsics, H, W,
+                       umax, vmax, gvertex, gnormal, dist_th, dot_th, c.pix_key, c.pt_pix, c.part_active, c.part_similar, ctr);
+    hipLaunchKernelGGL(corr_pass2_k, grid, dim3(CORR_T), 0, st, (const int *)c.pt_pix, counts, Nmax, (int64_t)H * W, gvertex, map_points,
+                       map_ccounts, (const unsigned long long *)c.pix_key, c.pix_n, (const int32_t *)c.part_similar, B * corr_blocks(Nmax),
+                       ctr);
+    GS_LAUNCH_CHECK("gs_pointfusion_update/correspond");
+    return GS_OK;
+}
+int fusion_merge_corr(void *state, const int32_t *ctr, const float *gvertex, const float *gnormal, const float *rgb, const float *alpha,
+                      int B, int H, int W, int Nmax, const int32_t *counts, float *points, float *normals, float *colors,
+                      float *ccounts, hipStream_t st) {
+    const CorrState c = corr_state_ptrs(state, B, H, W, Nmax);
+    hipLaunchKernelGGL(merge_corr_k, dim3(corr_blocks(Nmax), B), dim3(CORR_T), 0, st, (const int *)c.pt_pix, (const unsigned int *)c.pix_n,
+                       counts, ctr, Nmax, H * W, gvertex, gnormal, rgb, alpha, points, normals, colors, ccounts, c.part_u);
     GS_LAUNCH_CHECK("gs_pointfusion_update/merge");
     return GS_OK;
 }
-// unmatched valid pixels of batch element b appended behind the rows its arena already holds
-int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const float *depth, const float *const *h_src,
-                            const int *h_row_floats, float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended,
-                            int32_t *d_overflow, void *cws, hipStream_t st) {
-    unsigned long long *pix_key; unsigned int *pix_n; int *match;
-    fusion_state_ptrs((void *)state, B, H, W, &pix_key, &pix_n, &match);
+// unmatched valid pixels of batch element b appended behind the rows its arena holds; the row count itself advances
+// in fusion_finish (AppendWriter reads the count as the append offset, so it must not move before every b is written)
+int fusion_append_corr(void *state, int B, int H, int W, int Nmax, int b, const float *depth, const float *const *h_src,
+                       const int *h_row_floats, float *const *h_dst, const int32_t *d_count, int cap, int *d_total, void *cws,
+                       hipStream_t st) {
+    const CorrState c = corr_state_ptrs(state, B, H, W, Nmax);
     const int64_t HW = (int64_t)H * W;
     AppendWriter wr;
     wr.n_arrays = 4; wr.base = d_count; wr.cap = cap;
     for (int a = 0; a < 4; ++a) {
         wr.src[a] = (const uint32_t *)h_src[a]; wr.out[a] = (uint32_t *)h_dst[a]; wr.words[a] = h_row_floats[a];
     }
-    int *total = (int *)((char *)cws + compact_ws_bytes(HW));
-    AppendPredPix pred{depth + b * HW, pix_n + b * HW};
-    const int rc = compact_launch(HW, pred, wr, total, cws, st, "gs_pointfusion_update/append");
-    if (rc) return rc;
-    hipLaunchKernelGGL(append_count_k, dim3(1), dim3(64), 0, st, d_count, total, cap, d_appended, d_overflow);
-    GS_LAUNCH_CHECK("gs_pointfusion_update/append count");
+    AppendPredPix pred{depth + b * HW, c.pix_n + b * HW};
+    return compact_launch(HW, pred, wr, d_total, cws, st, "gs_pointfusion_update/append");
+}
+int fusion_finish(void *state, int B, int H, int W, int Nmax, int32_t *ctr, int32_t *counts, const int *totals, int cap,
+                  int32_t *appended, int32_t *stats, hipStream_t st) {
+    const CorrState c = corr_state_ptrs(state, B, H, W, Nmax);
+    hipLaunchKernelGGL(fuse_finish_k, dim3(1), dim3(1024), 0, st, (const int32_t *)c.part_active, (const int32_t *)c.part_u,
+                       B * corr_blocks(Nmax), ctr, counts, totals, B, cap, appended, stats);
+    GS_LAUNCH_CHECK("gs_pointfusion_update/finish");
     return GS_OK;
+}
+const unsigned int *fusion_corr_pix_n(const void *state, int B, int H, int W, int Nmax) {
+    return corr_state_ptrs((void *)state, B, H, W, Nmax).pix_n;
 }
 size_t fusion_tape_bytes(int B, int H, int W) {
     const size_t npix = (size_t)B * H * W;
@@ -523,14 +700,13 @@ static inline FusionTape fusion_tape_ptrs(void *tape, int B, int H, int W) {
     t.old = (float *)p;
     return t;
 }
-// after fusion_unique_match, before the merge: winners, pre-merge values and the row counts before the append
+// after fusion_correspond, before the merge: winners, pre-merge values and the row counts before the append
 int fusion_tape_record(const void *state, void *tape, int B, int H, int W, int Nmax, const int32_t *counts, const float *points,
                        const float *normals, const float *colors, const float *ccounts, hipStream_t st) {
-    unsigned long long *pix_key; unsigned int *pix_n; int *match;
-    fusion_state_ptrs((void *)state, B, H, W, &pix_key, &pix_n, &match);
+    const unsigned int *pix_n = fusion_corr_pix_n(state, B, H, W, Nmax);
     const FusionTape t = fusion_tape_ptrs(tape, B, H, W);
     const int64_t npix = (int64_t)B * H * W;
-    hipLaunchKernelGGL(tape_old_k, dim3(grid1d(npix)), dim3(256), 0, st, (const unsigned int *)pix_n, npix, H * W, Nmax, points, normals,
+    hipLaunchKernelGGL(tape_old_k, dim3(grid1d(npix)), dim3(256), 0, st, pix_n, npix, H * W, Nmax, points, normals,
                        colors, ccounts, t.pix_n, t.old);
     GS_LAUNCH_CHECK("gs_pointfusion_update_taped/record");
     GS_HIP(hipMemcpyAsync(t.n_before, counts, (size_t)B * 4, hipMemcpyDeviceToDevice, st), "gs_pointfusion_update_taped/counts");

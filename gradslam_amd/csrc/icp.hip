@@ -16,10 +16,11 @@
 //      v_readlane.  Rounding is monotone and the bound uses the distance's own operation order, so bound <= distance
 //      holds exactly in fp32: no epsilon, a chunk is skipped only on a STRICT '>', and the result is bit-identical to
 //      the brute-force scan (lexicographic (distance, index) minimum).
-//    * knn1_loop_k<true> (grid search with distance certificates, dense targets with search hints): every point
-//      examines the targets of the 3x3 ds-grid pixels around its window centre (staged in LDS) and a bound carried
-//      from association to association of one loop proves the window's best is the nearest neighbour; points whose
-//      proof fails take the chunk-box search again (see the comment above knn1_loop_k).
+//    * knn1_loop_k<true> (grid search with a geometric proof, dense targets with search hints): every point
+//      examines the targets of the 3x3 ds-grid pixels around the pixel it projects to (staged in LDS); every other
+//      target lies outside a pyramid through the camera centre, and the point's distance to the pyramid's faces proves
+//      that the window's best is the nearest neighbour; points whose proof fails take the chunk-box search (see
+//      cam_bound2 and the comment above knn1_loop_k).
 // J  gather + 29-term reduction, HBM/L2-bound at 40 algorithmic bytes per source point; wave
 //    butterflies + a fixed-order two-level tree (deterministic, no float atomics).  Fused into the association
 //    kernel's epilogue inside the loops; linearize_k / finalize44_k serve the stand-alone entry points.
@@ -37,6 +38,7 @@
 #include <vector>
 
 #include "gs_common.hpp"
+#include "gs_project.hpp"
 
 namespace gs {
 
@@ -53,10 +55,6 @@ constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
 constexpr int LIN_MAXB = 1024;  // max partial blocks of the stand-alone J kernel (best of 512/1024/2048 measured at 2^24 points)
 constexpr unsigned long long KEY_NONE = ~0ull;
-// Grid search: the exact search that establishes a certificate looks at every box within CERT_REACH x the tile's
-// loosest neighbour distance (squared: x CERT_REACH^2), not only at those that could hold a nearer neighbour -- the
-// boxes beyond bound the certificate radius from below by that much, the ones inside by their own per-point bounds.
-constexpr float CERT_REACH2 = 1.0f;
 constexpr int GRID_MIN_PER_PIXEL = 4;  // grid search from this many targets per ds-grid pixel (average) on
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int j) {
@@ -194,11 +192,10 @@ struct KnnShared {
     unsigned long long key[64];
     int cnt;
     float tbox[6];             // the source tile's AABB (lo.xyz, hi.xyz)
-    // grid search (knn1_loop_k<true>): certificate bookkeeping
-    unsigned int m_tile;       // min tile-level bound over the chunks the coarse pass pruned (float bits)
-    unsigned int mm[64];       // per lane: min bound / distance over everything outside its window (float bits)
+    // grid search (knn1_loop_k<true>)
     int win[WROWS][64];        // per lane: the packed window rows (LaneWin), from the staging waves
     int wflag[64];             // per lane: rel | full << 2 | window radius << 3
+    int centre[64];            // per lane: the window's centre pixel
     int band[2 * WBANDS + 1];  // staged bands: first slot x WBANDS, pool offset x WBANDS, pool fill
     float seed[2][64][4];      // the seed for either outcome of the step: target point, reference index bits
     union alignas(16) {
@@ -359,15 +356,13 @@ __device__ __forceinline__ int sel4(int k, int a0, int a1, int a2, int a3) { ret
 
 // Exact search over the chunk boxes for the lanes selected by `act`, seeded by sh.key (tile box in sh.tbox, both
 // visible): coarse pass with the tile's box and loosest bound, fine pass with per-lane bounds (see knn_tile).
-// GRID: chunks inside a lane's own window `win` were examined already and are skipped for that lane; the smallest
-// bound / distance the lane sees OUTSIDE its window is accumulated into sh.mm[lane] and -- for the chunks the
-// coarse pass prunes for the whole tile -- sh.m_tile: together the lane's certificate radius (knn_grid_tile).
+// GRID: chunks inside a lane's own window `win` were examined already and are skipped for that lane.
 // Ends with a barrier.
 template <bool GRID>
 __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, const bool ok, const bool act,
                                                  const float *__restrict__ scan, const int32_t *__restrict__ scan_orig,
                                                  const float *__restrict__ boxes, const float *__restrict__ sboxes /* or NULL */,
-                                                 const int nt, const float reach2 = 1.0f) {
+                                                 const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int n_scanned = 0;
     // the tile's box (from LDS) and its loosest bound (same 64 points in every wave -> same value)
@@ -376,8 +371,7 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
     key_unpack(sh.key[lane], bd0, bi0);
     const float tlx = sh.tbox[0], tly = sh.tbox[1], tlz = sh.tbox[2];
     const float thx = sh.tbox[3], thy = sh.tbox[4], thz = sh.tbox[5];
-    const float bdmax = wave_max_f(act ? bd0 : 0.0f) * (GRID ? reach2 : 1.0f);
-    float mm = INFINITY, mt = INFINITY;
+    const float bdmax = wave_max_f(act ? bd0 : 0.0f);
 
     const int nchunks = (nt + CHUNK - 1) / CHUNK;
 #ifdef GS_DIAG_STAMPS
@@ -400,10 +394,7 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
                 const float ey = fmaxf(fmaxf(b[1] - thy, tly - b[4]), 0.0f);
                 const float ez = fmaxf(fmaxf(b[2] - thz, tlz - b[5]), 0.0f);
                 const float lbs = (ex * ex + ey * ey) + ez * ez;
-                if (!(lbs <= bdmax)) {
-                    if (GRID) mt = fminf(mt, lbs);
-                    continue;
-                }
+                if (!(lbs <= bdmax)) continue;
             }
             const int c = c0 + lane;
             bool pass = false;
@@ -414,7 +405,6 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
                 const float ez = fmaxf(fmaxf(b[2] - thz, tlz - b[5]), 0.0f);
                 const float lbt = (ex * ex + ey * ey) + ez * ez;
                 pass = lbt <= bdmax;
-                if (GRID && !pass) mt = fminf(mt, lbt);
             }
             const unsigned long long m = __ballot(pass);
             if (m) {
@@ -463,7 +453,6 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
                 if (GRID) {
                     const bool live = act & !LaneWin::covers(sh, lane, cc * CHUNK);  // not examined by this lane yet
                     hit = live & (lb <= bd);
-                    mm = (live & !hit) ? fminf(mm, lb) : mm;
                 } else {
                     hit = act & (lb <= bd);
                 }
@@ -472,16 +461,13 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
                 const int m = min(CHUNK, nt - cc * CHUNK);
                 const float bdp = bd;
                 const int bip = bi;
-                float dmin = INFINITY;
                 for (int k = 0; k < m; ++k) {
                     const float d = dist2(s, rlane(q.x, l0 + k), rlane(q.y, l0 + k), rlane(q.z, l0 + k));
                     const int jj = __builtin_amdgcn_readlane(pj, l0 + k);
                     const bool better = (d < bd) | ((d == bd) & (jj < bi));
                     bd = better ? d : bd;
                     bi = better ? jj : bi;
-                    if (GRID) dmin = fminf(dmin, d);
                 }
-                if (GRID) mm = hit ? fminf(mm, dmin) : mm;  // these candidates lie outside the lane's window
                 if (ok && (bd < bdp || bi < bip)) atomicMin(&sh.key[lane], pack_key(bd, bi));
                 ++n_scanned;
             }
@@ -490,11 +476,6 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
 #endif
         }
         GS_ACCUM(t_fine, tf0);
-        if (GRID && r1 == nchunks) {  // last round: publish the certificate radii before the closing barrier
-            mt = wave_min_f(mt);
-            if (lane == 0) atomicMin(&sh.m_tile, fbits(mt));
-            if (act) atomicMin(&sh.mm[lane], fbits(mm));
-        }
         GS_TICK(tb1);
         __syncthreads();
         GS_ACCUM(t_bar, tb1);
@@ -516,14 +497,12 @@ __device__ __forceinline__ void knn_prune_search(KnnShared &sh, const f3 s, cons
 //   B  the pairs are dealt round-robin to the waves: lanes = the super-box's chunks, tested against the point's
 //      bound (chunks inside its window are skipped), survivors scanned at once, four per round, lanes = candidates.
 // For one or two stragglers this costs a fraction of the tile-level search -- what a converging loop needs once nearly
-// every certificate holds.  Same contract as knn_prune_search<true>: sh.mm[point] receives the smallest bound /
-// distance met outside the point's window.  sh.cnt must be zero on entry (all waves past their last use of the
+// every proof holds.  sh.cnt must be zero on entry (all waves past their last use of the
 // list's storage); ends with a barrier.  Returns false (block-uniform) when the pair list overflowed: nothing found is
 // final then and the caller must search again with knn_prune_search<true>.
 __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, const unsigned long long need_mask,
                                                  const float *__restrict__ scan, const int32_t *__restrict__ scan_orig,
-                                                 const float *__restrict__ boxes, const float *__restrict__ sboxes, const int nt,
-                                                 const float tau /* look into every super-box nearer than this (squared) */) {
+                                                 const float *__restrict__ boxes, const float *__restrict__ sboxes, const int nt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = (nt + CHUNK - 1) / CHUNK, nsb = (nchunks + SUPER - 1) / SUPER;
     for (unsigned long long rest = need_mask; rest; rest &= rest - 1) {  // phase A
@@ -532,7 +511,6 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
         float bd;
         int bi;
         key_unpack(sh.key[L], bd, bi);  // wave-uniform
-        float mm = INFINITY;
         for (int b0 = wave * 64; b0 < nsb; b0 += KNN_NW * 64) {
             const int sb = b0 + lane;
             bool hit = false;
@@ -542,8 +520,7 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
                 const float ey = fmaxf(fmaxf(b[1] - py, py - b[4]), 0.0f);
                 const float ez = fmaxf(fmaxf(b[2] - pz, pz - b[5]), 0.0f);
                 const float lb = (ex * ex + ey * ey) + ez * ez;
-                hit = lb <= fmaxf(bd, tau);
-                if (!hit) mm = fminf(mm, lb);
+                hit = lb <= bd;
             }
             const unsigned long long m = __ballot(hit);
             if (m) {
@@ -554,14 +531,12 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
                 if (hit && at < KNN_LIST) sh.u.a.list[at] = (L << 24) | sb;
             }
         }
-        mm = wave_min_f(mm);
-        if (lane == 0) atomicMin(&sh.mm[L], fbits(mm));
     }
     __syncthreads();
     // The list holds KNN_LIST (point, super-box) pairs IN TOTAL -- ~680 super-boxes (700 k targets) per point for six
     // points.  A far-away straggler (huge bound: every super-box passes) on a large target overflows it; which pairs
     // were dropped would depend on the atomics' arrival order, so nothing of this attempt is used: the caller runs the
-    // tile-level search for these points instead (block-uniform decision; sh.mm only ever holds valid lower bounds).
+    // tile-level search for these points instead (block-uniform decision).
     if (sh.cnt > KNN_LIST) {
         if (threadIdx.x == 0) atomicAdd(&g_loop_counts[3], 1u);
         __syncthreads();  // every wave has read sh.cnt before the caller's next search resets it
@@ -575,7 +550,6 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
         float bd;
         int bi;
         key_unpack(sh.key[L], bd, bi);
-        float mm = INFINITY;
         const int c = sb * SUPER + lane;
         bool hit = false;
         if (c < nchunks && !LaneWin::covers(sh, L, c * CHUNK)) {
@@ -585,7 +559,6 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
             const float ez = fmaxf(fmaxf(b[2] - p.z, p.z - b[5]), 0.0f);
             const float lb = (ex * ex + ey * ey) + ez * ez;
             hit = lb <= bd;
-            if (!hit) mm = fminf(mm, lb);
         }
         unsigned long long hits = __ballot(hit);
         while (hits) {  // four surviving chunks per round: lane l takes candidate l % CHUNK of the (l / CHUNK)-th of them
@@ -604,7 +577,6 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
                     const f3 q = ld3(scan, j);
                     const float d = dist2(p, q.x, q.y, q.z);
                     k = pack_key(d, scan_orig ? scan_orig[j] : j);
-                    mm = fminf(mm, d);  // outside the point's window by construction
                 }
             }
 #pragma unroll
@@ -617,8 +589,6 @@ __device__ __forceinline__ bool knn_point_search(KnnShared &sh, const f3 s, cons
                 key_unpack(k, bd, bi);
             }
         }
-        mm = wave_min_f(mm);
-        if (lane == 0) atomicMin(&sh.mm[L], fbits(mm));
     }
     __syncthreads();
     return true;
@@ -1224,23 +1194,20 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 // (out_slot < 0: the other one of the two ping-pong slots).  Seed: the current cloud's NN of the same source index
 // when there is one, else the sampled seed pass.
 //
-// GRID (all search hints given): the association is a GRID SEARCH WITH A DISTANCE CERTIFICATE.
-//   window      : the target is bucketed by ds-grid pixel (scan order, hints.pix_start).  Every lane examines ALL
-//                 targets of the 3 x 3 pixels around its window centre (three contiguous slot ranges, widened to whole
-//                 chunks), staged through LDS by coalesced loads issued before the folded step, so they cost no time.
-//                 The centre starts at the lane's own pixel and follows its neighbour (hints.tgt_pix) when that leaves
-//                 the window; the lanes of a tile move together, so their windows lie in at most four row bands,
-//                 each one contiguous slot range (row-major pixels), which share a pool of POOL staged points.
-//   certificate : what a lane has NOT examined is bounded from below -- the first association (and any later one a
-//                 lane needs) runs the exact chunk-box search for it and records m = the smallest bound / distance it
-//                 met outside the lane's window, together with the lane's position s_ref and window centre.  Later
-//                 associations of the same loop move the point a little (ICP steps): by the triangle inequality every
-//                 unexamined target is at least sqrt(m) - |s - s_ref| away, so if the best of the (same, fully
-//                 examined) window is strictly closer -- with a 1e-4 relative margin on every term, orders of magnitude
-//                 above fp32 rounding -- it IS the nearest neighbour, tie-break included, and no box is touched.  Lanes
-//                 that fail the test take the exact search again, restricted to them, and get a fresh certificate.
-// The result is the brute-force scan's in every case; only the cost differs (a later association of a converging
-// loop examines ~100 candidates per point instead of ~800 and tests no boxes).
+// GRID (all search hints given): the association is a GRID SEARCH WITH A GEOMETRIC PROOF.
+//   window : the target is bucketed by ds-grid pixel of the camera it was selected with (scan order, hints.pix_start).
+//            Every lane examines ALL targets of the 3 x 3 pixels around the pixel its point projects to (three
+//            contiguous slot ranges, widened to whole chunks), staged through LDS by coalesced loads issued before the
+//            folded step, so they cost no time.  The lanes of a tile move together, so their windows lie in at most
+//            four row bands, each one contiguous slot range (row-major pixels), which share a pool of POOL staged points.
+//   proof  : every target OUTSIDE the window projects at least 2 ds - 0.5 image pixels from the window's centre pixel,
+//            i.e. lies beyond one of four planes through the camera centre; the point's distance to the nearest of those
+//            planes bounds its distance to all of them from below (cam_bound2).  A window best strictly inside that
+//            bound IS the nearest neighbour, tie-break included, and no box is touched: nothing is carried from launch
+//            to launch, the first association of a loop is proven like every other.  Lanes that fail (no map point
+//            within centimetres: new image regions, depth edges) take the exact chunk-box search, restricted to them.
+// The result is the brute-force scan's in every case; only the cost differs (~100 candidates per point at ten targets
+// per pixel instead of ~800 and no box tests).
 // What stays the same for every launch of one loop lives in the workspace (written once by icp_prepare_k), not in
 // the kernel arguments: at ~100 scalar registers a 1024-thread block no longer shares its CU with a second one (the
 // hardware admits floor(800 / (ceil(sgpr / 16) 16 + 16)) waves per SIMD: 8 up to 80 SGPRs, 7 from 82 on -- whatever
@@ -1248,18 +1215,15 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 struct LoopConst {
     const float *user_src, *tgt, *nrm, *boxes, *sboxes;
     const int32_t *d_ns, *d_nt;
-    float *trace, *out_T, *cert;
-    int32_t *cert_c;
+    float *trace, *out_T;
     const int32_t *guard_count;  // small tiles only if ALSO *guard_count >= guard_min (the map's actual size; NULL: no such guard)
     gs_icp_hints hints;
     GradParams gp;
     float thresh;
     int grid_min_per_pixel;
     int grid_radius_max;   // largest window radius tried (2 or 1)
-    float cert_reach2;     // CERT_REACH2, tunable for measurements
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
-    int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a certificate -> every association searches exactly
-    int recentre_keep;     // the window follows the neighbour once it is more than this many pixels from the centre (0 / 1)
+    int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a proof -> every association searches exactly
     int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each).  The host
                            // hands in the size for a DENSE target (loop_tile_points); icp_prepare_k replaces it by 64 when
                            // the target's actual count says sparse -- a decision made from device-side counts only
@@ -1267,7 +1231,55 @@ struct LoopConst {
     int guard_min;
     int loop_blocks;          // blocks of every association launch of this loop (the small tiles must cover the cloud)
     int grid_variant;         // this loop launches knn1_loop_k<true> (for the loop counters only)
+    // the camera the targets were bucketed with (hints.cam_pose / cam_K as icp_prepare_k read them): world -> camera as
+    // project_point (gs_project.hpp) applies it, and the pinhole constants.  cam_ok = 0: K is not a plain pinhole
+    // matrix (skew, a projective third row ...) -> no geometric proof, every association searches exactly.
+    float camR[9], camT[3], fx, fy, cx, cy;
+    int cam_ok;
 };
+
+// world point -> camera coordinates of the bucketing camera, with project_point's arithmetic (gs_project.hpp)
+__device__ __forceinline__ f3 cam_point(const LoopConst *C, const f3 p) {
+    return f3{dot3_fma(p.x, p.y, p.z, C->camR[0], C->camR[3], C->camR[6]) + C->camT[0],
+              dot3_fma(p.x, p.y, p.z, C->camR[1], C->camR[4], C->camR[7]) + C->camT[1],
+              dot3_fma(p.x, p.y, p.z, C->camR[2], C->camR[5], C->camR[8]) + C->camT[2]};
+}
+// the ds-grid pixel (row-major id) whose centre is nearest to the projection of p (clamped into the grid; any value is
+// safe: the proof below is evaluated against whatever centre was chosen)
+__device__ __forceinline__ int cam_cell(const LoopConst *C, const f3 p) {
+    const f3 q = cam_point(C, p);
+    const float zs = (q.z != 0.0f) ? q.z : 1.0f;
+    const float ds = (float)C->hints.ds;
+    const float u = ((C->fx * q.x + C->cx * q.z) / zs) / ds, v = ((C->fy * q.y + C->cy * q.z) / zs) / ds;
+    const int cc = (int)fminf(fmaxf(rintf(u), 0.0f), (float)(C->hints.grid_w - 1));
+    const int cr = (int)fminf(fmaxf(rintf(v), 0.0f), (float)(C->hints.grid_h - 1));
+    return cr * C->hints.grid_w + cc;
+}
+// GEOMETRIC PROOF.  Squared lower bound on the distance from s to every target OUTSIDE the (2R+1)^2 grid pixels around
+// `centre`.  A target sits in grid pixel (r, c) iff its projection (u, v) rounds to the image pixel (r ds, c ds), so
+// |u - c ds| <= 0.5 and |v - r ds| <= 0.5 (+ ~1e-3 of fp32 error in the bucketing's own projection).  A target outside the
+// window therefore has u >= U+ = (cc + R + 1) ds - 0.5, or u <= U- = (cc - R - 1) ds + 0.5, or the same in v.  With
+// z > 0 (only points in front of the camera are targets), u >= U+ means fx x + (cx - U+) z >= 0: a half-space whose
+// boundary plane passes through the camera centre -- and likewise for the other three sides.  The distance from s to a
+// half-space it is not in is the distance to its plane; the minimum over the (up to four) sides that can hold targets
+// at all -- beyond the image border there are none -- bounds the distance to every outside target from below.  Rigid
+// transforms preserve distances, so the bound is evaluated in camera coordinates.  Margins: 0.52 instead of 0.5 px,
+// 0.1 % + 10 um off the bound: orders of magnitude above fp32 rounding of the terms.  0 = no proof.
+__device__ __forceinline__ float cam_bound2(const LoopConst *C, const f3 s, const int centre, const int R) {
+    const f3 q = cam_point(C, s);
+    const int Wd = C->hints.grid_w, Hd = C->hints.grid_h;
+    const int cr = centre / Wd, cc = centre - cr * Wd;
+    const float ds = (float)C->hints.ds;
+    const float hw = (float)(R + 1) * ds - 0.52f;
+    const float uc = (float)cc * ds, vc = (float)cr * ds;
+    float L = INFINITY;
+    if (cc + R + 1 < Wd) { const float a = C->cx - (uc + hw); L = fminf(L, -(C->fx * q.x + a * q.z) / sqrtf(C->fx * C->fx + a * a)); }
+    if (cc - R - 1 >= 0) { const float a = C->cx - (uc - hw); L = fminf(L, (C->fx * q.x + a * q.z) / sqrtf(C->fx * C->fx + a * a)); }
+    if (cr + R + 1 < Hd) { const float a = C->cy - (vc + hw); L = fminf(L, -(C->fy * q.y + a * q.z) / sqrtf(C->fy * C->fy + a * a)); }
+    if (cr - R - 1 >= 0) { const float a = C->cy - (vc - hw); L = fminf(L, (C->fy * q.y + a * q.z) / sqrtf(C->fy * C->fy + a * a)); }
+    L = L * 0.999f - 1e-5f;
+    return L > 0.0f ? L * L : 0.0f;  // (NaN compares false: no proof)
+}
 
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
@@ -1328,10 +1340,14 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     } else if (grid && tile_live) {
         const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
         const int h = ok ? min(max(C->hints.src_pix[i], 0), nc - 1) : 0;
+        // Window centre: the grid pixel the point projects to.  The point itself is only known once the step (wave 0,
+        // concurrently) has produced dT -- but it is within millimetres of the cloud the PREVIOUS launch wrote, whatever
+        // the step decides (first launch: the caller's cloud under the initial transform, exactly).  The centre only
+        // selects which window is examined; the proof below is evaluated for the point's actual position against it.
         int c = h;
-        if (ok && !first) {
-            const int cc = C->cert_c[i] & 0xffffff;  // (the window radius the certificate was made with rides in the top byte)
-            c = cc < nc ? cc : h;
+        if (ok && C->cam_ok) {
+            const f3 pp = first ? xform(S_in->dT, ld3(C->user_src, i)) : ld3(B.P(look_slot >= 0 ? look_slot : 1 - S_in->p_cur), i);
+            c = cam_cell(C, pp);
         }
         float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
@@ -1446,9 +1462,9 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 sh.win[r][lane] = packed;
             }
             sh.wflag[lane] = min(rel, 2) | (full ? 4 : 0) | (R << 3);
+            sh.centre[lane] = c;
             sh.key[lane] = KEY_NONE;
-            sh.mm[lane] = fbits(INFINITY);
-            if (lane == 0) { sh.m_tile = fbits(INFINITY); sh.cnt = 0; sh.band[2 * WBANDS] = used; }
+            if (lane == 0) { sh.cnt = 0; sh.band[2 * WBANDS] = used; }
             if (lane < WBANDS) {
                 int bb = bbase[0], bo = boff[0];
 #pragma unroll
@@ -1492,18 +1508,11 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     }
     unsigned long long key;
     bool need = false;
-    float m_new = 0.0f;
     int rel = 2;  // grid search: the lane's centre row relative to the tile's first (0 / 1), | 4 = window fully staged
     if (grid) {
         GS_STAMP(0);
         rel = sh.wflag[lane];
-        // the lane's certificate, and the seed: one real candidate per lane, fetched for either outcome of the step
-        float4 cf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        int cert_R = 0;
-        if (ok && !first) {
-            cf = *reinterpret_cast<const float4 *>(C->cert + 4 * (int64_t)i);
-            cert_R = C->cert_c[i] >> 24;
-        }
+        // the seed: one real candidate per lane, fetched for either outcome of the step
         if (wave == 0) {
             unsigned long long k0 = KEY_NONE;
             if (ok) {
@@ -1545,49 +1554,21 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         float bd;
         int bi;
         key_unpack(sh.key[lane], bd, bi);
-        // certificate: unexamined targets are >= sqrt(m) - |s - s_ref| away (margins: see the kernel comment)
-        const float moved = sqrtf(dist2(s, cf.x, cf.y, cf.z));
-        const float reach = sqrtf(cf.w) * 0.9999f - moved * 1.0001f;
-        // (the same window: same centre by construction, at least the radius the certificate was made with, all of it staged)
-        const bool proven = !C->cert_off & ((rel & 4) != 0) & ((rel >> 3) >= cert_R) & (cf.w > 0.0f) & (reach > 0.0f) & (bd * 1.0001f < reach * reach);
+        // proof: every target outside the window is at least sqrt(cam_bound2) away (see there); the window was examined
+        // completely (rel & 4), so a best strictly inside the bound IS the nearest neighbour, tie-break included
+        const float bound2 = (ok && C->cam_ok) ? cam_bound2(C, s, sh.centre[lane], rel >> 3) : 0.0f;
+        const bool proven = !C->cert_off & ((rel & 4) != 0) & (bd * 1.0001f < bound2);
         need = ok & !proven;
-#ifdef GS_DIAG_STAMPS
-        {   // why certificates fail (diagnostic build): lanes per reason, and the tile's mean radii in micrometres
-            const bool c_full = (rel & 4) != 0, c_rad = (rel >> 3) >= cert_R, c_m = cf.w > 0.0f, c_reach = reach > 0.0f;
-            const unsigned long long n1 = __popcll(__ballot(ok & !c_full)), n2 = __popcll(__ballot(ok & c_full & !c_rad)),
-                                     n3 = __popcll(__ballot(ok & c_full & c_rad & !c_m)), n4 = __popcll(__ballot(ok & c_full & c_rad & c_m & !c_reach)),
-                                     n5 = __popcll(__ballot(ok & c_full & c_rad & c_m & c_reach & !proven));
-            GS_COUNT(13, n1 | (n2 << 8) | (n3 << 16) | (n4 << 24) | (n5 << 32) | ((unsigned long long)(rel >> 3) << 40));
-            const float nn = fmaxf((float)__popcll(__ballot(ok & c_m)), 1.0f);
-            const unsigned long long um_m = (unsigned long long)(1e6f * wave_sum((ok & c_m) ? sqrtf(cf.w) : 0.0f) / nn),
-                                     um_mv = (unsigned long long)(1e6f * wave_sum((ok & c_m) ? moved : 0.0f) / nn),
-                                     um_bd = (unsigned long long)(1e6f * wave_sum((ok & c_m) ? sqrtf(bd) : 0.0f) / nn);
-            GS_COUNT(14, (um_m & 0xfffff) | ((um_mv & 0xfffff) << 20) | ((um_bd & 0xfffff) << 40));
-        }
-#endif
         const unsigned long long need_mask = __ballot(need);  // the same 64 lanes in every wave: block-uniform
         GS_COUNT(12, (unsigned long long)__popcll(need_mask));
         bool tile_search = __popcll(need_mask) > 6;
         if (!tile_search && need_mask) {
-            tile_search = !knn_point_search(sh, s, need_mask, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt,
-                                            C->cert_reach2 * wave_max_f(ok ? bd : 0.0f));  // ends with a barrier
-            m_new = bitsf(sh.mm[lane]);
+            tile_search = !knn_point_search(sh, s, need_mask, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt);  // ends with a barrier
         }
         if (tile_search) {
             tile_box(sh, s, need);
             __syncthreads();
-            knn_prune_search<true>(sh, s, ok, need, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt, C->cert_reach2);  // ends with a barrier
-            m_new = fminf(bitsf(sh.mm[lane]), bitsf(sh.m_tile));
-#ifdef GS_DIAG_STAMPS
-            {   // which of the two radii decides the certificate, and how large they are (micrometres, tile means)
-                const float mt_ = bitsf(sh.m_tile), ml_ = bitsf(sh.mm[lane]);
-                const unsigned long long n_tile = __popcll(__ballot(need & (mt_ < ml_)));
-                const float nn = fmaxf((float)__popcll(need_mask), 1.0f);
-                const unsigned long long um_t = (unsigned long long)fminf(1e6f * sqrtf(mt_), 1e6f),
-                                         um_l = (unsigned long long)fminf(1e6f * wave_sum(need ? fminf(sqrtf(ml_), 1.0f) : 0.0f) / nn, 1e6f);
-                GS_COUNT(15, n_tile | (um_t << 8) | (um_l << 32));
-            }
-#endif
+            knn_prune_search<true>(sh, s, ok, need, C->hints.scan_points, C->hints.scan_orig, C->boxes, C->sboxes, nt);  // ends with a barrier
         }
         GS_STAMP(2);
         key = ok ? sh.key[lane] : KEY_NONE;
@@ -1616,22 +1597,6 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
     if (wave == 0) {
         if (ok) best[i] = key;
-        if (grid && need && key != KEY_NONE) {
-            // fresh certificate.  It holds for THIS window; a neighbour outside the window moves the centre there and
-            // leaves the lane without a certificate until the next exact search has bounded the new window's outside.
-            const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h, R = rel >> 3;
-            int centre = min(max(C->hints.src_pix[i], 0), nc - 1);
-            if (!first) {
-                const int cc = C->cert_c[i] & 0xffffff;
-                centre = cc < nc ? cc : centre;
-            }
-            const int cstar = C->hints.tgt_pix ? min(max(C->hints.tgt_pix[(uint32_t)(key & 0xffffffffu)], 0), nc - 1) : centre;
-            // the neighbour should sit in the inner part of the window (one pixel of margin to its rim)
-            const int keep = C->recentre_keep;
-            const bool inside = abs(cstar / Wd - centre / Wd) <= keep && abs(cstar % Wd - centre % Wd) <= keep;
-            *reinterpret_cast<float4 *>(C->cert + 4 * (int64_t)i) = make_float4(s.x, s.y, s.z, (inside && (rel & 4)) ? m_new : 0.0f);
-            C->cert_c[i] = (inside ? centre : cstar) | (R << 24);
-        }
         float acc[NACC];
 #pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -1691,6 +1656,21 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
             if (lc.grid_variant && pixels > 0 && (int64_t)*lc.d_nt >= (int64_t)lc.grid_min_per_pixel * pixels) atomicAdd(&g_loop_counts[1], 1u);
         }
         reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
+    }
+    if (blockIdx.x == 0) {  // the bucketing camera, after the plain copy above (same words)
+        __syncthreads();
+        if (threadIdx.x == 0 && lc.hints.cam_pose && lc.hints.cam_K && lc.hints.ds > 0) {
+            const float *T = lc.hints.cam_pose, *K = lc.hints.cam_K;
+            const Cam c = make_cam(T, K);
+            for (int q = 0; q < 9; ++q) lc_out->camR[q] = c.R[q];
+            for (int q = 0; q < 3; ++q) lc_out->camT[q] = c.tinv[q];
+            lc_out->fx = K[0]; lc_out->fy = K[5]; lc_out->cx = K[2]; lc_out->cy = K[6];
+            // project_point divides (K row 0 / 1) . [x y z 1] by (K row 2) . [x y z 1]: the proof's planes assume the
+            // plain pinhole form u = fx x / z + cx, v = fy y / z + cy
+            const bool pinhole = K[1] == 0.0f && K[3] == 0.0f && K[4] == 0.0f && K[7] == 0.0f && K[8] == 0.0f && K[9] == 0.0f &&
+                                 K[10] == 1.0f && K[11] == 0.0f && K[0] != 0.0f && K[5] != 0.0f;
+            lc_out->cam_ok = pinhole ? 1 : 0;
+        }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int i = 0; i < 16; ++i) {
@@ -1828,8 +1808,6 @@ struct IcpWs {
     LoopBufs B;
     float *partials[2];
     float *boxes, *sboxes;  // chunk boxes, and one box per SUPER chunks
-    float *cert;         // grid search: (max_ns, 4) certificate per source point (knn1_loop_k<true>)
-    int32_t *cert_c;     // grid search: (max_ns) window centre of every source point
     LoopConst *lc;       // the loop's constants (knn1_loop_k reads them from here, not from its arguments)
 };
 static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out) {
@@ -1840,7 +1818,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
     const size_t oPart = take((size_t)loop_blocks_max(max_ns) * NACC * 4), oPart1 = take((size_t)loop_blocks_max(max_ns) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt)), oSBox = take((size_t)cdiv(max_nt > 0 ? max_nt : 1, 1024) * 6 * 4);
-    const size_t oCert = take((size_t)max_ns * 16), oCertC = take((size_t)max_ns * 4), oLc = take(sizeof(LoopConst));
+    const size_t oLc = take(sizeof(LoopConst));
     if (ws && out) {
         char *p = (char *)ws;
         out->S[0] = (IcpState *)(p + oS); out->S[1] = (IcpState *)(p + oS1);
@@ -1851,8 +1829,6 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
         out->partials[0] = (float *)(p + oPart); out->partials[1] = (float *)(p + oPart1);
         out->boxes = (float *)(p + oBox);
         out->sboxes = (float *)(p + oSBox);
-        out->cert = (float *)(p + oCert);
-        out->cert_c = (int32_t *)(p + oCertC);
         out->lc = (LoopConst *)(p + oLc);
     }
     return off;
@@ -1890,7 +1866,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
                    const float *compose_right = nullptr, float *compose_out = nullptr,
                    int dense_hint = -1 /* caller's knowledge of the target's density: 1 dense, 0 sparse, -1 judge by max_nt */,
                    const int32_t *guard_count = nullptr, int guard_min = 0 /* see LoopConst::guard_count */) {
-    gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
     GS_REQUIRE(src && d_ns && tgt && nrm && d_nt && out_T, "%s: NULL argument", name);  // init_T NULL = identity
@@ -1937,18 +1913,17 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
     static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 1;
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
-    static const int recentre_keep = getenv("GS_RECENTRE_KEEP") ? atoi(getenv("GS_RECENTRE_KEEP")) : 1;
-    static const float cert_reach2 = getenv("GS_CERT_REACH2") ? (float)atof(getenv("GS_CERT_REACH2")) : CERT_REACH2;
     // all hints given: grid search with distance certificates (knn1_loop_k<true>); GS_NO_GRID_SEARCH=1 keeps the
     // chunk-box search for every association (same results; for A/B measurements and tests)
     static const bool grid_off = getenv("GS_NO_GRID_SEARCH") != nullptr;
     // ... and only where the target can be dense enough for it (the kernel checks the actual count again): the grid
     // variant carries more registers and 32 bytes of scratch, 1.4 us per launch on a sparse target
     const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
-                             hints.grid_w > 0 && hints.grid_h > 0 && (g_grid_mode == 2 || dense);
-    const LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, w.cert, w.cert_c, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax,
-                       cert_reach2, 0, 0, cert_off, recentre_keep, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
-                       guard_min, (int)kgrid.x, grid_search ? 1 : 0};
+                             hints.cam_pose && hints.cam_K && hints.ds > 0 && hints.grid_w > 0 && hints.grid_h > 0 &&
+                             (g_grid_mode == 2 || dense);
+    LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax,
+                 0, 0, cert_off, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
+                 guard_min, (int)kgrid.x, grid_search ? 1 : 0, {0}, {0}, 0.0f, 0.0f, 0.0f, 0.0f, 0};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);

@@ -41,11 +41,26 @@ __device__ __forceinline__ f3 vertex_of(const Kinv4 k, int h, int w, float d) {
     return f3{(x * d) * m, (y * d) * m, (1.0f * d) * m};
 }
 
+// What the PointFusion update lets ride on this pass over the pixels (slam.hip, fusion.hip; all optional): the sample
+// confidence alpha = get_alpha(local vertex) (slam/fusionutils.py:69-73, the arithmetic of alpha_k below), the
+// "no candidate / no winner" initialisation of the correspondence stage's per-pixel state, and the zeroing of its counter
+// block -- three launches (alpha_k, two memsets) that become stores of a kernel that visits every pixel anyway.
+struct VnExtra {
+    float *alpha;                  // (B*L*H*W) or NULL
+    float alpha_den, alpha_eps;    // 2 sigma^2, lower clamp
+    unsigned long long *pix_key;   // (B*L*H*W) or NULL: set to ~0
+    unsigned int *pix_n;           // (B*L*H*W) or NULL: set to ~0
+    int32_t *zero;                 // n_zero words zeroed by the first block, or NULL
+    int n_zero;
+};
+
 __global__ __launch_bounds__(TW *TH) void vertex_normal_k(const float *__restrict__ depth, const float *__restrict__ Ks,
                                                           const float *__restrict__ poses, int L, int H, int W,
                                                           float *__restrict__ vertex, float *__restrict__ normal,
-                                                          float *__restrict__ gvertex, float *__restrict__ gnormal) {
+                                                          float *__restrict__ gvertex, float *__restrict__ gnormal, VnExtra ex) {
     __shared__ float sd[TH + 1][TW + 1];
+    if (ex.zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < ex.n_zero; i += TW * TH) ex.zero[i] = 0;
     const int bl = blockIdx.z;  // b*L + l
     const int b = bl / L;
     const int w0 = blockIdx.x * TW, h0 = blockIdx.y * TH;
@@ -97,6 +112,12 @@ __global__ __launch_bounds__(TW *TH) void vertex_normal_k(const float *__restric
     n = f3{(n.x / nn) * m, (n.y / nn) * m, (n.z / nn) * m};
 
     const int64_t pix = (int64_t)bl * H * W + (int64_t)h * W + w;
+    if (ex.alpha) {  // alpha_k's arithmetic on the local vertex
+        const float ss = (v.x * v.x + v.y * v.y) + v.z * v.z;
+        ex.alpha[pix] = fminf(fmaxf(expf((-ss) / ex.alpha_den), ex.alpha_eps), 1.01f);
+    }
+    if (ex.pix_key) ex.pix_key[pix] = ~0ull;
+    if (ex.pix_n) ex.pix_n[pix] = ~0u;
     if (vertex) st3(vertex, pix, v);
     if (normal) st3(normal, pix, n);
     if (gvertex || gnormal) {
@@ -474,10 +495,28 @@ int gs_vertex_normal_maps(const float *depth, const float *intrinsics, const flo
     GS_REQUIRE((int64_t)B * L <= 65535, "gs_vertex_normal_maps: B*L must be <= 65535");
     dim3 grid(cdiv(W, TW), cdiv(H, TH), B * L);
     hipLaunchKernelGGL(vertex_normal_k, grid, dim3(TW * TH), 0, (hipStream_t)stream, depth, intrinsics, poses, L, H, W,
-                       vertex, normal, gvertex, gnormal);
+                       vertex, normal, gvertex, gnormal, VnExtra{nullptr, 1.0f, 0.0f, nullptr, nullptr, nullptr, 0});
     GS_LAUNCH_CHECK("gs_vertex_normal_maps");
     return GS_OK;
 }
+
+}  // extern "C"
+
+namespace gs {
+// the maps of ONE frame per batch element for the PointFusion update, with its riders (VnExtra): global maps and alpha
+// out, per-pixel correspondence state initialised, counter block zeroed
+int vertex_normal_maps_fusion(const float *depth, const float *intrinsics, const float *poses, int B, int H, int W, float *gvertex,
+                              float *gnormal, float *alpha, float sigma, float eps, unsigned long long *pix_key, unsigned int *pix_n,
+                              int32_t *zero, int n_zero, hipStream_t st) {
+    dim3 grid(cdiv(W, TW), cdiv(H, TH), B);
+    hipLaunchKernelGGL(vertex_normal_k, grid, dim3(TW * TH), 0, st, depth, intrinsics, poses, 1, H, W, (float *)nullptr,
+                       (float *)nullptr, gvertex, gnormal, VnExtra{alpha, 2.0f * (sigma * sigma), eps, pix_key, pix_n, zero, n_zero});
+    GS_LAUNCH_CHECK("gs_pointfusion_update/maps");
+    return GS_OK;
+}
+}  // namespace gs
+
+extern "C" {
 
 size_t gs_vertex_normal_maps_backward_ws_bytes(int B, int L, int H, int W) {
     return align_up((size_t)B * L * H * W * 3 * sizeof(float), 256) * 2 +

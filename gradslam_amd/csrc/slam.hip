@@ -157,18 +157,24 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     return off;
 }
 
-// fusion.hip: fused forms of the unique / merge / append stages (one memset instead of two memsets + a fill, the
-// match table written by the unique stage's compaction, the append mask read from its per-pixel winners)
-size_t fusion_state_bytes(int B, int H, int W, int Nmax);
-int fusion_unique_match(const int64_t *rows, const uint8_t *keep, const int32_t *d_n_rows, int64_t max_rows, const float *gvertex,
-                        int B, int H, int W, const float *map_points, const float *map_ccounts, int Nmax, int64_t *out_rows,
-                        int32_t *out_count, void *state, void *cws, hipStream_t st);
-int fusion_merge_prebuilt(const void *state, const int32_t *d_n_rows, const float *gvertex, const float *gnormal, const float *rgb,
-                          const float *alpha, int B, int H, int W, int Nmax, const int32_t *counts, float *points, float *normals,
-                          float *colors, float *ccounts, hipStream_t st);
-int fusion_append_unmatched(const void *state, int B, int H, int W, int b, const float *depth, const float *const *h_src,
-                            const int *h_row_floats, float *const *h_dst, int32_t *d_count, int cap, int32_t *d_appended,
-                            int32_t *d_overflow, void *cws, hipStream_t st);
+// fusion.hip: the fused correspondence chain of the PointFusion update (no tables: 4 bytes per map point), the merge that
+// reads it, the append of the unmatched pixels and the update's last launch; maps.hip: the maps kernel with its riders
+size_t fusion_corr_state_bytes(int B, int H, int W, int Nmax);
+void fusion_corr_init_ptrs(void *state, int B, int H, int W, int Nmax, unsigned long long **pix_key, unsigned int **pix_n);
+int fusion_correspond(void *state, const float *map_points, const float *map_normals, const float *map_ccounts, const int32_t *counts,
+                      int B, int Nmax, const float *poses, const float *intrinsics, int H, int W, const float *gvertex,
+                      const float *gnormal, float dist_th, float dot_th, int32_t *ctr, hipStream_t st);
+int fusion_merge_corr(void *state, const int32_t *ctr, const float *gvertex, const float *gnormal, const float *rgb, const float *alpha,
+                      int B, int H, int W, int Nmax, const int32_t *counts, float *points, float *normals, float *colors,
+                      float *ccounts, hipStream_t st);
+int fusion_append_corr(void *state, int B, int H, int W, int Nmax, int b, const float *depth, const float *const *h_src,
+                       const int *h_row_floats, float *const *h_dst, const int32_t *d_count, int cap, int *d_total, void *cws,
+                       hipStream_t st);
+int fusion_finish(void *state, int B, int H, int W, int Nmax, int32_t *ctr, int32_t *counts, const int *totals, int cap,
+                  int32_t *appended, int32_t *stats, hipStream_t st);
+int vertex_normal_maps_fusion(const float *depth, const float *intrinsics, const float *poses, int B, int H, int W, float *gvertex,
+                              float *gnormal, float *alpha, float sigma, float eps, unsigned long long *pix_key, unsigned int *pix_n,
+                              int32_t *zero, int n_zero, hipStream_t st);
 
 size_t fusion_tape_bytes(int B, int H, int W);
 int fusion_tape_record(const void *state, void *tape, int B, int H, int W, int Nmax, const int32_t *counts, const float *points,
@@ -185,33 +191,30 @@ int append_valid_pixels(int n_arrays, const float *depth_b, int64_t HW, const fl
 
 // ------------------------------------------------------------------ PointFusion map update on an arena
 struct FuseWs {
-    float *V, *N, *gV, *gN, *alpha;  // (B,H,W,3) x4, (B,H,W)
-    int64_t *rows;                   // (B*Nmax, 4) active rows
-    int64_t *urows;                  // (B*H*W, 4) unique rows
-    uint8_t *keep;                   // (B*Nmax)
-    void *state;                     // unique stage: per-pixel keys / winners + per-point match table
-    int32_t *nrows, *ucnt, *appended, *overflow;  // (1),(1),(B),(1)
-    float *max_dot;                  // (1)
+    float *gV, *gN, *alpha;          // (B,H,W,3) x2, (B,H,W)
+    void *state;                     // correspondence stage: per-pixel keys / winners, per-point pixel, per-block counts
+    int32_t *ctr;                    // counter block: active, unique, overflow, max_dot bits, any-similar flag
+    int32_t *appended;               // (B)
+    int *totals;                     // (B) rows each sequence's append pass selected
     void *sub;
     size_t sub_bytes;
 };
+constexpr int kCtrWords = 64;  // counter block (zeroed by the maps kernel): ctr[0..], appended at +64, totals at +128
 static size_t fuse_layout(int B, int H, int W, int Nmax, void *ws, FuseWs *out) {
-    const size_t npix = (size_t)B * H * W, npt = (size_t)B * Nmax;
+    const size_t npix = (size_t)B * H * W;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    const size_t oV = take(npix * 12), oN = take(npix * 12), ogV = take(npix * 12), ogN = take(npix * 12), oA = take(npix * 4);
-    const size_t oR = take(npt * 32), oU = take(npix * 32), oK = take(npt), oM = take(fusion_state_bytes(B, H, W, Nmax));
-    const size_t oC = take(256 + (size_t)B * 4);
-    size_t sub = gs_project_active_ws_bytes(B, Nmax);
-    sub = std::max(sub, gs_compact_ws_bytes((int64_t)B * H * W) + 256);
+    const size_t ogV = take(npix * 12), ogN = take(npix * 12), oA = take(npix * 4);
+    const size_t oM = take(fusion_corr_state_bytes(B, H, W, Nmax));
+    const size_t oC = take((size_t)(kCtrWords + 2 * 64) * 4);
+    const size_t sub = gs_compact_ws_bytes((int64_t)H * W) + 256;
     const size_t oS = take(sub);
     if (ws && out) {
         char *p = (char *)ws;
-        out->V = (float *)(p + oV); out->N = (float *)(p + oN); out->gV = (float *)(p + ogV); out->gN = (float *)(p + ogN);
-        out->alpha = (float *)(p + oA); out->rows = (int64_t *)(p + oR); out->urows = (int64_t *)(p + oU);
-        out->keep = (uint8_t *)(p + oK); out->state = p + oM;
+        out->gV = (float *)(p + ogV); out->gN = (float *)(p + ogN);
+        out->alpha = (float *)(p + oA); out->state = p + oM;
         int32_t *c = (int32_t *)(p + oC);
-        out->nrows = c; out->ucnt = c + 1; out->overflow = c + 2; out->max_dot = (float *)(c + 3); out->appended = c + 64;
+        out->ctr = c; out->appended = c + kCtrWords; out->totals = (int *)(c + kCtrWords + 64);
         out->sub = p + oS; out->sub_bytes = sub;
     }
     return off;
@@ -378,7 +381,8 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
             const float *src = w.src + (size_t)b * capS * 3;
             const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
             const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
-                                     w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds)};
+                                     w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds),
+                                     prev_poses + 16 * b, intrinsics + 16 * b, ds};
             // the loop's last launch also writes out_poses[b] = T . prev_poses[b]
             const int r = icp_localize_run(use_grad_lm, src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, numiters, damp, dist_thresh,
                                            lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)s, nullptr,
@@ -479,39 +483,34 @@ static int pointfusion_update_impl(const float *depth, const float *rgb, const f
     hipStream_t st = (hipStream_t)stream;
     FuseWs w;
     fuse_layout(B, H, W, Nmax, ws, &w);
-    const int64_t npix = (int64_t)B * H * W, npt = (int64_t)B * Nmax;
     int rc;
-    GS_HIP(hipMemsetAsync(w.nrows, 0, 256 + (size_t)B * 4, st), name);  // counters, flags, max_dot
-    // live frame under its final pose; sample confidence from the local vertex map (fusionutils.py:650-652)
-    if ((rc = gs_vertex_normal_maps(depth, intrinsics, poses, B, 1, H, W, w.V, w.N, w.gV, w.gN, stream))) return rc;
-    if ((rc = gs_get_alpha(w.V, npix, sigma, 1e-7f, w.alpha, stream))) return rc;
-    // find_correspondences (fusionutils.py:549-577): active -> similar -> best unique per pixel
-    if ((rc = gs_project_active(map_points, map_counts, B, Nmax, poses, intrinsics, H, W, 0, w.rows, w.nrows, w.sub, w.sub_bytes,
-                                stream))) return rc;
-    if ((rc = gs_fusion_similar(w.rows, w.nrows, npt, w.gV, w.gN, H, W, map_points, map_normals, Nmax, dist_th, dot_th, w.keep,
-                                w.max_dot, stream))) return rc;
-    if ((rc = fusion_unique_match(w.rows, w.keep, w.nrows, npt, w.gV, B, H, W, map_points, map_ccounts, Nmax, w.urows, w.ucnt, w.state,
-                                  w.sub, st))) return rc;
+    // live frame under its final pose: global maps, the sample confidence from the LOCAL vertex map
+    // (fusionutils.py:650-652), and -- riding on the same pass over the pixels -- the correspondence stage's per-pixel
+    // state and the counter block initialised (no memset, no alpha launch)
+    unsigned long long *pix_key; unsigned int *pix_n;
+    fusion_corr_init_ptrs(w.state, B, H, W, Nmax, &pix_key, &pix_n);
+    if ((rc = vertex_normal_maps_fusion(depth, intrinsics, poses, B, H, W, w.gV, w.gN, w.alpha, sigma, 1e-7f, pix_key, pix_n, w.ctr,
+                                        kCtrWords + 2 * 64, st))) return rc;
+    // find_correspondences (fusionutils.py:549-577): active -> similar -> best unique per pixel, without the tables
+    if ((rc = fusion_correspond(w.state, map_points, map_normals, map_ccounts, map_counts, B, Nmax, poses, intrinsics, H, W, w.gV, w.gN,
+                                dist_th, dot_th, w.ctr, st))) return rc;
     // differentiable form: the winners and the matched rows' values before the merge go to the tape
     if (tape && (rc = fusion_tape_record(w.state, tape, B, H, W, Nmax, map_counts, map_points, map_normals, map_colors, map_ccounts, st)))
         return rc;
     // fuse_with_map (fusionutils.py:654-720): merge in place, then append the unmatched valid pixels
-    if ((rc = fusion_merge_prebuilt(w.state, w.ucnt, w.gV, w.gN, rgb, w.alpha, B, H, W, Nmax, map_counts, map_points, map_normals,
-                                    map_colors, map_ccounts, st))) return rc;
+    if ((rc = fusion_merge_corr(w.state, w.ctr, w.gV, w.gN, rgb, w.alpha, B, H, W, Nmax, map_counts, map_points, map_normals, map_colors,
+                                map_ccounts, st))) return rc;
     const int64_t HW = (int64_t)H * W;
     for (int b = 0; b < B; ++b) {
         const float *src[4] = {w.gV + b * HW * 3, w.gN + b * HW * 3, rgb + b * HW * 3, w.alpha + b * HW};
         float *dst[4] = {map_points + (size_t)b * Nmax * 3, map_normals + (size_t)b * Nmax * 3, map_colors + (size_t)b * Nmax * 3,
                          map_ccounts + (size_t)b * Nmax};
         const int widths[4] = {3, 3, 3, 1};
-        if ((rc = fusion_append_unmatched(w.state, B, H, W, b, depth, src, widths, dst, map_counts + b, Nmax, w.appended + b,
-                                          w.overflow, w.sub, st))) return rc;
+        if ((rc = fusion_append_corr(w.state, B, H, W, Nmax, b, depth, src, widths, dst, map_counts + b, Nmax, w.totals + b, w.sub, st)))
+            return rc;
     }
+    if ((rc = fusion_finish(w.state, B, H, W, Nmax, w.ctr, map_counts, w.totals, Nmax, w.appended, stats, st))) return rc;
     if (tape && (rc = fusion_tape_appended(tape, B, H, W, w.appended, st))) return rc;
-    if (stats) {
-        hipLaunchKernelGGL(fuse_stats_k, dim3(1), dim3(64), 0, st, w.nrows, w.ucnt, w.overflow, w.max_dot, w.appended, B, stats);
-        GS_LAUNCH_CHECK(name);
-    }
     return GS_OK;
 }
 
@@ -661,7 +660,8 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
     }
     for (int b = 0; b < B; ++b) {
         const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, tp.src_pix + (size_t)b * capS,
-                                 w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds)};
+                                 w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds),
+                                 prev_poses + 16 * b, intrinsics + 16 * b, ds};
         if ((rc = icp_localize_run(use_grad_lm, tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
                                    w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, numiters, damp, dist_thresh, lambda_max, Bp, B2, nu,
                                    &hints, tp.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)stream, tp.icp + (size_t)b * tp.icp_bytes,

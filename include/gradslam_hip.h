@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 #define GS_OK 0
 #define GS_ERR_INVALID_ARG (-1)
 #define GS_ERR_WORKSPACE_TOO_SMALL (-2)
@@ -226,15 +226,21 @@ typedef struct gs_icp_hints {
     const int32_t *scan_orig;   /* (nt) reference index (into tgt) of every scan slot; required with scan_points */
     const int32_t *src_pix;     /* (ns) ds-grid pixel id r*grid_w+c of every source point */
     const int32_t *pix_start;   /* (grid_h*grid_w+1) first scan slot of every pixel (scan order = pixel order) */
-    const int32_t *tgt_pix;     /* (nt) ds-grid pixel of every target, reference order (optional: lets a source point
-                                   whose neighbour has left the 3x3 pixels around its own re-centre its window) */
+    const int32_t *tgt_pix;     /* (nt) ds-grid pixel of every target, reference order (optional; unused since ABI 3) */
     int32_t grid_w, grid_h;
-    /* With scan_points, scan_orig, src_pix and pix_start all given the loops associate by GRID SEARCH WITH
-     * DISTANCE CERTIFICATES (gs_set_grid_search): every source point examines all targets of the 3x3 pixels around
-     * its window centre, and a lower bound on everything else -- established by one exact chunk-box search and
-     * carried from association to association of the loop through the triangle inequality -- proves that the
-     * window's best is the nearest neighbour; points whose proof fails take the exact search again.  Hints never
-     * change a result (tested against the brute-force scan with consistent and with scrambled hints). */
+    /* ABI 3: the camera the targets were bucketed with -- pose (4x4, camera -> world) and intrinsics (4x4) on the
+     * device, and the grid step: a target sits in pixel (r, c) iff its projection under (cam_pose, cam_K), rounded
+     * half-to-even as find_active_map_points does (slam/fusionutils.py:247-282), is the image pixel (r ds, c ds).
+     * gs_build_icp_target / gs_bucket_by_pixel produce exactly that from the pose and intrinsics they are given. */
+    const float *cam_pose, *cam_K;
+    int32_t ds;
+    /* With ALL of the above given (tgt_pix excepted) the loops associate by GRID SEARCH WITH A GEOMETRIC PROOF
+     * (gs_set_grid_search): every source point examines all targets of the 3x3 grid pixels around the pixel it projects
+     * to; every other target projects at least 2 ds - 0.5 image pixels away from that pixel's centre, i.e. lies outside a
+     * pyramid through the camera centre, and the point's distance to the pyramid's faces bounds its distance to all of
+     * them from below -- a window best strictly inside that bound IS the nearest neighbour.  Points whose proof fails
+     * (no map point within centimetres) take the exact chunk-box search.  Hints never change a result (tested against
+     * the brute-force scan with consistent and with scrambled hints). */
 } gs_icp_hints;
 
 /* point_to_plane_ICP (odometry/icputils.py:310-367) as one call on the device (section comment above). */

@@ -958,19 +958,21 @@ def test_odd_image_shapes_vs_oracle(gs, H, W, ds, B):
 
 
 # ------------------------------------------------------------------ grid search with distance certificates
-def _grid_scene(seed, Hd=60, Wd=80, ds=4, per_cell=6, motion=0.004, shuffle_hints=False, duplicates=False, with_tgt_pix=True):
+def _grid_scene(seed, Hd=60, Wd=80, ds=4, per_cell=6, motion=0.004, shuffle_hints=False, duplicates=False, with_tgt_pix=True,
+                posed=False, flip_fy=False):
     """A synthetic ds-grid scene: up to `per_cell` targets per ds-grid pixel on a wavy wall (reference order
     shuffled, like a map), one source point per pixel with drop-outs, displaced by a small rigid motion.  Returns
     (src, src_pix, tgt, nrm, hints tensors) on the device."""
     g = torch.Generator().manual_seed(seed)
     fx = 525.0 * (Wd * ds) / 640.0
+    fy = -fx if flip_fy else fx  # (the reference's own fixture has fy < 0)
     cx, cy = (Wd * ds - 1) / 2.0, (Hd * ds - 1) / 2.0
     wall = lambda x, y: 2.0 + 0.3 * torch.sin(2.0 * x) * torch.cos(2.0 * y)
 
     def backproject(u, v, jitter):
-        x, y = (u - cx) / fx * 2.0, (v - cy) / fx * 2.0
+        x, y = (u - cx) / fx * 2.0, (v - cy) / fy * 2.0
         z = wall(x, y) + jitter
-        return torch.stack([(u - cx) / fx * z, (v - cy) / fx * z, z], -1)
+        return torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1)
 
     rr, cc = torch.meshgrid(torch.arange(Hd), torch.arange(Wd), indexing="ij")
     cell = (rr * Wd + cc).reshape(-1)
@@ -995,12 +997,24 @@ def _grid_scene(seed, Hd=60, Wd=80, ds=4, per_cell=6, motion=0.004, shuffle_hint
     a = 0.5 * motion
     R = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=torch.float32)
     src = (src @ R.t() + torch.tensor([motion, -0.5 * motion, 0.3 * motion])).contiguous()
-    if shuffle_hints:  # inconsistent hints must cost speed only
+    if shuffle_hints:  # inconsistent per-point hints must cost speed only
         sc = sc[torch.randperm(sc.shape[0], generator=g)]
+    # the camera the targets were bucketed with (ABI 3: part of the hints; the buckets above ARE its ds-grid pixels)
+    K = torch.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, cx, cy
+    pose = torch.eye(4)
+    if posed:  # everything moved rigidly into a world frame: camera -> world = pose
+        a, b2 = 0.4, -0.25
+        Ry = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=torch.float32)
+        Rx = torch.tensor([[1, 0, 0], [0, math.cos(b2), -math.sin(b2)], [0, math.sin(b2), math.cos(b2)]], dtype=torch.float32)
+        pose[:3, :3] = Ry @ Rx
+        pose[:3, 3] = torch.tensor([0.7, -0.3, 1.1])
+        move = lambda x: (x @ pose[:3, :3].t() + pose[:3, 3]).contiguous()
+        src, tgt, nrm = move(src), move(tgt), (nrm @ pose[:3, :3].t()).contiguous()
     dev = lambda x, dt=None: (x if dt is None else x.to(dt)).contiguous().to(DEV)
     return dict(src=dev(src), src_pix=dev(sc, torch.int32), tgt=dev(tgt), nrm=dev(nrm.contiguous()), scan_points=dev(tgt[order]),
                 scan_orig=dev(order, torch.int32), pix_start=dev(pix_start, torch.int32),
-                tgt_pix=dev(tcell, torch.int32) if with_tgt_pix else None, Wd=Wd, Hd=Hd)
+                tgt_pix=dev(tcell, torch.int32) if with_tgt_pix else None, Wd=Wd, Hd=Hd, cam_pose=dev(pose), cam_K=dev(K), ds=ds)
 
 
 def _taped_loop_with_hints(gs, sc, numiters, grad_lm, init_T=None):
@@ -1012,10 +1026,12 @@ def _taped_loop_with_hints(gs, sc, numiters, grad_lm, init_T=None):
 
     class Hints(ctypes.Structure):
         _fields_ = [("scan_points", ctypes.c_void_p), ("scan_orig", ctypes.c_void_p), ("src_pix", ctypes.c_void_p),
-                    ("pix_start", ctypes.c_void_p), ("tgt_pix", ctypes.c_void_p), ("grid_w", ctypes.c_int32), ("grid_h", ctypes.c_int32)]
+                    ("pix_start", ctypes.c_void_p), ("tgt_pix", ctypes.c_void_p), ("grid_w", ctypes.c_int32), ("grid_h", ctypes.c_int32),
+                    ("cam_pose", ctypes.c_void_p), ("cam_K", ctypes.c_void_p), ("ds", ctypes.c_int32)]
 
     h = Hints(sc["scan_points"].data_ptr(), sc["scan_orig"].data_ptr(), sc["src_pix"].data_ptr(), sc["pix_start"].data_ptr(),
-              sc["tgt_pix"].data_ptr() if sc.get("tgt_pix") is not None else None, sc["Wd"], sc["Hd"])
+              sc["tgt_pix"].data_ptr() if sc.get("tgt_pix") is not None else None, sc["Wd"], sc["Hd"],
+              sc["cam_pose"].data_ptr(), sc["cam_K"].data_ptr(), sc["ds"])
     src, tgt, nrm = sc["src"], sc["tgt"], sc["nrm"]
     ns, nt = src.shape[0], tgt.shape[0]
     T0 = (torch.eye(4) if init_T is None else init_T).to(DEV).contiguous()
@@ -1050,7 +1066,7 @@ def _taped_loop_with_hints(gs, sc, numiters, grad_lm, init_T=None):
 
 
 @pytest.mark.parametrize("case", ["plain", "dense", "big_motion", "big_motion_dense", "big_motion_no_tgt_pix", "shuffled_hints",
-                                  "duplicates", "gradlm", "sparse", "two_rows_per_tile"])
+                                  "duplicates", "gradlm", "sparse", "two_rows_per_tile", "posed_camera", "negative_fy", "posed_dense_big_motion"])
 def test_grid_search_every_association_is_the_bruteforce_scan(gs, case):
     """The grid search with distance certificates (knn1_loop_k<true>) must return, for EVERY association launch of a
     loop, exactly what the brute-force scan returns on that launch's cloud: same packed (distance, index) keys.  Cases:
@@ -1061,7 +1077,8 @@ def test_grid_search_every_association_is_the_bruteforce_scan(gs, case):
     kw = dict(plain={}, dense=dict(per_cell=40, Hd=30, Wd=40), big_motion=dict(motion=0.06),
               big_motion_dense=dict(motion=0.05, per_cell=24, Hd=40, Wd=60), big_motion_no_tgt_pix=dict(motion=0.06, with_tgt_pix=False),
               shuffled_hints=dict(shuffle_hints=True), duplicates=dict(duplicates=True), gradlm={}, sparse=dict(per_cell=1),
-              two_rows_per_tile=dict(Hd=90, Wd=24, motion=0.03))[case]
+              two_rows_per_tile=dict(Hd=90, Wd=24, motion=0.03), posed_camera=dict(posed=True), negative_fy=dict(flip_fy=True, motion=0.01),
+              posed_dense_big_motion=dict(posed=True, flip_fy=True, motion=0.04, per_cell=16, Hd=40, Wd=60))[case]
     sc = _grid_scene(seed=len(case), **kw)
     grad_lm = 1 if case == "gradlm" else 0
     for mode in (2, 0):  # with certificates (whatever the density) / chunk boxes only: both exact, and equal to each other

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_native.SIGNATURES) == names
-    assert lib.gs_abi_version() == 2
+    assert lib.gs_abi_version() == 3
 
 
 def test_icp_launch_geometry_fits_the_workspace():
