@@ -47,7 +47,7 @@ constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving t
 constexpr int KNN_BT = KNN_NW * 64;
 constexpr int KNN_COARSE = 512; // target points sampled by the seed pass when no seed is given
 constexpr int CHUNK = 16;       // target points per AABB chunk
-constexpr int WROWS = 3;        // grid search: rows of the window (radius 1; radius 2 = WROWS 5 was measured and bought nothing)
+constexpr int WROWS = 5;        // grid search: rows of the widest window (radius 2, for sparse targets; dense ones use radius 1)
 constexpr int WBANDS = WROWS + 1;  // row bands a tile stages at most (its lanes sit in two adjacent rows)
 constexpr int SUPER = 64;       // chunks per super-box (= 1024 target points = one block of icp_prepare_k)
 constexpr int KNN_LIST = 4096;  // chunk boxes handled per round (capacity of the LDS survivor list)
@@ -1222,6 +1222,7 @@ struct LoopConst {
     float thresh;
     int grid_min_per_pixel;
     int grid_radius_max;   // largest window radius tried (2 or 1)
+    int grid_r2_below_per_pixel;  // radius 2 while the target holds fewer than this many points per ds-grid pixel
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
     int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a proof -> every association searches exactly
     int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each).  The host
@@ -1422,7 +1423,12 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             }
             return fits;
         };
-        if (C->grid_radius_max < 2 || WROWS < 5 || !lay_bands(2)) { R = 1; lay_bands(1); }
+        // Radius 2 (5 x 5 pixels) on a SPARSE target: with about one target per pixel the nearest one may be the
+        // neighbouring pixel's (a hole, a depth edge) and the 3 x 3 window's bound (~5 pixel pitches of the image) is then
+        // too tight; the 5 x 5 window bounds everything outside by ~9.5 pitches and costs 25 candidates.  On a dense target
+        // the nearest neighbour is millimetres away and 3 x 3 (a third of the candidates) proves it.
+        const bool sparse = (int64_t)nt < (int64_t)C->grid_r2_below_per_pixel * nc;
+        if (C->grid_radius_max < 2 || WROWS < 5 || !sparse || !lay_bands(2)) { R = 1; lay_bands(1); }
         // staging loads first (they are the long ones), the per-lane rows behind them
         constexpr int ST = KNN_BT - 64, NR = (POOL + ST - 1) / ST;
         float4 sreg[NR];
@@ -1774,7 +1780,7 @@ static inline void prof_mark(int tag, int which, hipStream_t st) {
 
 bool profiling_enabled() { return g_prof.on; }
 
-static int g_grid_mode = 1;  // gs_set_grid_search
+static int g_grid_mode = getenv("GS_GRID_MODE") ? atoi(getenv("GS_GRID_MODE")) : 1;  // gs_set_grid_search (environment: measurements)
 static int g_tile_points = 0;  // gs_set_tile_points (0 = automatic)
 
 // Source points per block of the loops' association kernel (knn1_loop_k).  A 1024-thread block is one co-residency
@@ -1911,7 +1917,8 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const int fb = min(cdiv(max_ns, 256), 256);
 
     const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
-    static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 1;
+    static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 2;
+    static const int grid_r2_below = getenv("GS_GRID_R2_BELOW") ? atoi(getenv("GS_GRID_R2_BELOW")) : 3;
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
     // all hints given: grid search with distance certificates (knn1_loop_k<true>); GS_NO_GRID_SEARCH=1 keeps the
     // chunk-box search for every association (same results; for A/B measurements and tests)
@@ -1921,7 +1928,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
                              hints.cam_pose && hints.cam_K && hints.ds > 0 && hints.grid_w > 0 && hints.grid_h > 0 &&
                              (g_grid_mode == 2 || dense);
-    LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax,
+    LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax, grid_r2_below,
                  0, 0, cert_off, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
                  guard_min, (int)kgrid.x, grid_search ? 1 : 0, {0}, {0}, 0.0f, 0.0f, 0.0f, 0.0f, 0};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
