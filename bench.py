@@ -131,6 +131,65 @@ def hbm_roofline_linearize(gs, dev, n_pts=1 << 24, reps=20):
                     "= achieved / 6290)"}
 
 
+def hbm_linearize_real_associations(gs, dev, side=4096, reps=10):
+    """The same kernel (J at 2^24 points) with REAL associations instead of `arange +- 8`: source = a side x side depth image
+    of the synthetic wall back-projected (image order, like the ICP clouds), target = the same wall seen from a camera moved
+    by a few pixels' worth and slightly rotated, nearest neighbours from an actual exact search (gs_knn1).  The gather then
+    has the locality a real association has -- neighbours of neighbouring pixels, with the row-to-row jumps and the local
+    disorder of a real search -- not the best case."""
+    from gradslam_amd import ops
+    from gradslam_amd._native import call, ptr, stream, workspace, ws_bytes
+
+    n_pts = side * side
+    f = 525.0 * side / 640.0
+    cxy = (side - 1) / 2.0
+    v, u = torch.meshgrid(torch.arange(side, device=dev, dtype=torch.float32), torch.arange(side, device=dev, dtype=torch.float32), indexing="ij")
+    wall = lambda x, y: 2.0 + 0.3 * torch.sin(2.0 * x) * torch.cos(2.0 * y)
+
+    def cloud(du, dv, rot):
+        uu, vv = u + du, v + dv
+        x, y = (uu - cxy) / f * 2.0, (vv - cxy) / f * 2.0
+        z = wall(x, y)
+        p = torch.stack([(uu - cxy) / f * z, (vv - cxy) / f * z, z], -1).reshape(-1, 3)
+        R = torch.tensor([[math.cos(rot), 0, math.sin(rot)], [0, 1, 0], [-math.sin(rot), 0, math.cos(rot)]], device=dev)
+        return (p @ R.t()).contiguous()
+
+    tgt = cloud(0.0, 0.0, 0.0)
+    src = cloud(2.37, -1.21, 0.0007)
+    nrm = torch.nn.functional.normalize(torch.stack([-0.6 * torch.ones_like(tgt[:, 0]), 0.1 * torch.ones_like(tgt[:, 0]), -torch.ones_like(tgt[:, 0])], -1), dim=-1).contiguous()
+    t0 = time.perf_counter()
+    best = ops.knn1_raw(src, tgt)
+    torch.cuda.synchronize()
+    t_search = time.perf_counter() - t0
+    idx = best & 0xffffffff
+    jump = (idx[1:] - idx[:-1]).abs().float()
+    out = torch.empty(44, device=dev)
+    ws = workspace(ws_bytes("gs_icp_linearize_ws_bytes", n_pts), dev, "linearize")
+    d_n = ops.dev_int(n_pts, dev)
+    run = lambda: call("gs_icp_linearize", ptr(src), ptr(d_n), n_pts, ptr(tgt), ptr(nrm), ptr(best), -1.0, ptr(out), ptr(ws),
+                       ws.numel(), stream())
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        run()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    med = ms[len(ms) // 2]
+    kept = [m for m in ms if m <= 3.0 * med]
+    avg = sum(kept) / len(kept)
+    alg = 40.0 * n_pts
+    return {"n_points": n_pts, "avg_launch_ms": round(avg, 4), "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "unit": "GB/s",
+            "frac": round(alg / (avg * 1e-3) / 8e12, 4), "bound": "hbm", "peak": 8000.0,
+            "association": {"search_s": round(t_search, 3), "median_index_jump": float(jump.median()), "p99_index_jump": float(jump.quantile(0.99)),
+                            "monotone_fraction": round(float((idx[1:] >= idx[:-1]).float().mean()), 4)},
+            "note": "gs_icp_linearize at 2^24 points with nearest neighbours from an exact search of a shifted, slightly rotated view "
+                    "of the same surface ({}x{} image order): 40 algorithmic bytes per point, HIP events on the launch stream".format(side, side)}
+
+
 def aux_pointfusion(gs, dev, raw, n_frames=30):
     """Auxiliary, NOT part of `value`: forward frames/s of the full PointFusion step (localise + map update,
     BASELINE configs[2] shape) over a short synthetic sequence, map growing from empty."""
@@ -269,6 +328,24 @@ def aux_c3_full_length(gs, dev, n_frames=200):
                 torch.cuda.synchronize()
                 best = max(best, n_frames / (time.perf_counter() - t0))
             out["forward_fps_" + odom] = round(best, 2)
+            if odom == "icp":
+                # the headline's localisation step in the state configs[2] lives in: the SAME call (ICPSLAM._localize, 10 LM
+                # iterations) against the map after 200 frames, previous frame = frame 199 under its recovered pose
+                prev = gs.RGBDImages(cd[:, -1:].contiguous(), dd[:, -1:].contiguous(), Kd, poses[:, -1:].contiguous())
+                lives = [(cd[:, s:s + 1].contiguous(), dd[:, s:s + 1].contiguous()) for s in (n_frames - 1, n_frames - 2)]
+                for i in range(6):
+                    one_step(gs, slam, pcs, prev, lives[i % 2], Kd)
+                torch.cuda.synchronize()
+                reps = 50
+                t0 = time.perf_counter()
+                for i in range(reps):
+                    one_step(gs, slam, pcs, prev, lives[i % 2], Kd)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                out["c2_on_dense_map"] = {"ms_per_step": round(1e3 * dt, 4), "frames_per_s": round(1.0 / dt, 1),
+                                          "map_points": int(pcs.num_points_per_pointcloud.item()),
+                                          "note": "the c2 step (`value`) against the map after {} frames instead of the one-frame map: "
+                                                  "projection of every map point, a target of ~10 points per ds-grid pixel".format(n_frames)}
         out["final_map_points"] = int(pcs.num_points_per_pointcloud.item())
         del pcs, poses
     for rep in range(3):  # the first passes warm the allocator (7.7 GB of tapes per pass); the last one is reported
@@ -426,6 +503,12 @@ def main():
     n_knn, ms_knn = prof_read(nv, 0)
     nv.lib().gs_profile_enable(0)
 
+    # how many ranks really took part, counted THROUGH the collective the poses travel on (N > 1: RCCL = backend "nccl")
+    backend_name = torch.distributed.get_backend() if world > 1 else "none (single process)"
+    one = torch.ones(1, dtype=torch.float64, device="cpu" if backend_name == "gloo" else dev)
+    if world > 1:
+        torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+    ranks_seen = int(one.item())
     red_dev = "cpu" if (world > 1 and torch.distributed.get_backend() == "gloo") else dev
     tmax = torch.tensor(dts, dtype=torch.float64, device=red_dev)   # every repeat: MAX over ranks, then the median
     if world > 1:
@@ -454,6 +537,7 @@ def main():
             "value": round(world * args.steps / dt, 3),
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen, "collective_backend": backend_name,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -484,6 +568,11 @@ def main():
             line["roofline"] = hbm_roofline_linearize(gs, dev)
         except Exception as e:  # pragma: no cover
             line["roofline"] = {"error": str(e)}
+        if world == 1 and not os.environ.get("GS_BENCH_SHORT"):
+            try:
+                line["roofline_real_associations"] = hbm_linearize_real_associations(gs, dev)
+            except Exception as e:  # pragma: no cover
+                line["roofline_real_associations"] = {"error": str(e)}
         if world == 1:
             try:
                 line["aux"] = aux_pointfusion(gs, dev, raw)

@@ -30,6 +30,19 @@ struct pred_has_block_init : std::false_type {};
 template <class P>
 struct pred_has_block_init<P, std::void_t<decltype(&P::block_init)>> : std::true_type {};
 
+// a Pred may split itself into fetch(i) -> Item (the loads; i is always a valid index) and test(item, i): the kernels then
+// FETCH all of a thread's items before testing any, so that the memory round trips of its kCI items overlap instead of
+// running back to back (a predicate with an early-out before its load serialises them: 8 dependent trips per thread for
+// the projection).  A Writer may then provide put(item, i, pos) to reuse what the predicate fetched.
+template <class P, class = void>
+struct pred_has_fetch : std::false_type {};
+template <class P>
+struct pred_has_fetch<P, std::void_t<typename P::Item>> : std::true_type {};
+template <class W, class = void>
+struct writer_has_put : std::false_type {};
+template <class W>
+struct writer_has_put<W, std::void_t<decltype(&W::put)>> : std::true_type {};
+
 constexpr int kCT = 256;               // threads per block
 constexpr int kCI = 4;                 // consecutive items per thread
 constexpr int kCB = kCT * kCI;         // items per block
@@ -41,16 +54,29 @@ static inline size_t compact_ws_bytes(int64_t n) { return align_up(2 * sizeof(in
 template <class Pred>
 __global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts) {
     __shared__ int sm[kCT / 64];
-    if constexpr (pred_has_block_init<Pred>::value) {
-        pred.block_init(0);
-        __syncthreads();
-    }
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     int c = 0;
+    if constexpr (pred_has_fetch<Pred>::value) {
+        typename Pred::Item it[kCI];  // (fetched before the block's preparation: its loads overlap these)
 #pragma unroll
-    for (int k = 0; k < kCI; ++k) {
-        const int64_t i = base + k;
-        if (i < n && pred(i)) ++c;
+        for (int k = 0; k < kCI; ++k) it[k] = pred.fetch(base + k < n ? base + k : 0);
+        if constexpr (pred_has_block_init<Pred>::value) {
+            pred.block_init(0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < kCI; ++k)
+            if (base + k < n && pred.test(it[k], base + k)) ++c;
+    } else {
+        if constexpr (pred_has_block_init<Pred>::value) {
+            pred.block_init(0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < kCI; ++k) {
+            const int64_t i = base + k;
+            if (i < n && pred(i)) ++c;
+        }
     }
     c = wave_sum_i(c);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
@@ -132,6 +158,29 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     bool f[kCI];
     int c = 0;
+    if constexpr (pred_has_fetch<Pred>::value) {
+        typename Pred::Item it[kCI];
+#pragma unroll
+        for (int k = 0; k < kCI; ++k) it[k] = pred.fetch(base + k < n ? base + k : 0);
+#pragma unroll
+        for (int k = 0; k < kCI; ++k) {
+            f[k] = (base + k < n) && pred.test(it[k], base + k);
+            c += f[k] ? 1 : 0;
+        }
+        int total;
+        int pos = block_base + block_excl_scan<kCT>(c, sm, &total);
+#pragma unroll
+        for (int k = 0; k < kCI; ++k) {
+            if (f[k]) {
+                if constexpr (writer_has_put<Writer>::value) writer.put(it[k], base + k, (int64_t)pos);
+                else writer(base + k, (int64_t)pos);
+                ++pos;
+            } else if constexpr (writer_has_skip<Writer>::value) {
+                if (base + k < n) writer.skip(base + k);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kCI; ++k) {
         const int64_t i = base + k;

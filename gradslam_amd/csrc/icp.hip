@@ -47,7 +47,8 @@ constexpr int KNN_NW = 16;      // pruned search: waves per block, ALL serving t
 constexpr int KNN_BT = KNN_NW * 64;
 constexpr int KNN_COARSE = 512; // target points sampled by the seed pass when no seed is given
 constexpr int CHUNK = 16;       // target points per AABB chunk
-constexpr int WROWS = 5;        // grid search: rows of the widest window (radius 2, for sparse targets; dense ones use radius 1)
+constexpr int WROWS = 3;        // grid search: rows of the window (radius 1; radius 2 = WROWS 5 with its six bands costs ~1 us per launch
+                                // on a dense target and gains nothing on a sparse one: 22.9 against 21.1 us per launch at c2, r03f)
 constexpr int WBANDS = WROWS + 1;  // row bands a tile stages at most (its lanes sit in two adjacent rows)
 constexpr int SUPER = 64;       // chunks per super-box (= 1024 target points = one block of icp_prepare_k)
 constexpr int KNN_LIST = 4096;  // chunk boxes handled per round (capacity of the LDS survivor list)
@@ -188,6 +189,11 @@ __global__ __launch_bounds__(64) void tgt_boxes_k(const float *__restrict__ tgt,
 constexpr int POOL = 4096;  // grid search: target points staged in LDS per tile (all window rows together): 64 KiB; two such
                              // blocks share a CU (tools/micro/coresidency.hip: up to 80 KiB each)
 
+// the bucketing camera: rotation / translation world -> camera in project_point's layout, pinhole constants, grid
+struct CamK {
+    float R[9], T[3], fx, fy, cx, cy;
+    int ds, Wd, Hd;
+};
 struct KnnShared {
     unsigned long long key[64];
     int cnt;
@@ -196,6 +202,7 @@ struct KnnShared {
     int win[WROWS][64];        // per lane: the packed window rows (LaneWin), from the staging waves
     int wflag[64];             // per lane: rel | full << 2 | window radius << 3
     int centre[64];            // per lane: the window's centre pixel
+    CamK cam;                  // the bucketing camera (copied once per block: the proof reads it at LDS, not scalar-cache, latency)
     int band[2 * WBANDS + 1];  // staged bands: first slot x WBANDS, pool offset x WBANDS, pool fill
     float seed[2][64][4];      // the seed for either outcome of the step: target point, reference index bits
     union alignas(16) {
@@ -1235,26 +1242,28 @@ struct LoopConst {
     // the camera the targets were bucketed with (hints.cam_pose / cam_K as icp_prepare_k read them): world -> camera as
     // project_point (gs_project.hpp) applies it, and the pinhole constants.  cam_ok = 0: K is not a plain pinhole
     // matrix (skew, a projective third row ...) -> no geometric proof, every association searches exactly.
-    float camR[9], camT[3], fx, fy, cx, cy;
+    CamK cam;
     int cam_ok;
+    int32_t *cells;           // (2, cells_stride): the ds-grid pixel every point of the cloud an association wrote projects to,
+    int cells_stride;         // by launch parity -- where the NEXT launch centres its windows (knn1_loop_k)
 };
 
 // world point -> camera coordinates of the bucketing camera, with project_point's arithmetic (gs_project.hpp)
-__device__ __forceinline__ f3 cam_point(const LoopConst *C, const f3 p) {
-    return f3{dot3_fma(p.x, p.y, p.z, C->camR[0], C->camR[3], C->camR[6]) + C->camT[0],
-              dot3_fma(p.x, p.y, p.z, C->camR[1], C->camR[4], C->camR[7]) + C->camT[1],
-              dot3_fma(p.x, p.y, p.z, C->camR[2], C->camR[5], C->camR[8]) + C->camT[2]};
+__device__ __forceinline__ f3 cam_point(const CamK &k, const f3 p) {
+    return f3{dot3_fma(p.x, p.y, p.z, k.R[0], k.R[3], k.R[6]) + k.T[0],
+              dot3_fma(p.x, p.y, p.z, k.R[1], k.R[4], k.R[7]) + k.T[1],
+              dot3_fma(p.x, p.y, p.z, k.R[2], k.R[5], k.R[8]) + k.T[2]};
 }
 // the ds-grid pixel (row-major id) whose centre is nearest to the projection of p (clamped into the grid; any value is
 // safe: the proof below is evaluated against whatever centre was chosen)
-__device__ __forceinline__ int cam_cell(const LoopConst *C, const f3 p) {
-    const f3 q = cam_point(C, p);
+__device__ __forceinline__ int cam_cell(const CamK &k, const f3 p) {
+    const f3 q = cam_point(k, p);
     const float zs = (q.z != 0.0f) ? q.z : 1.0f;
-    const float ds = (float)C->hints.ds;
-    const float u = ((C->fx * q.x + C->cx * q.z) / zs) / ds, v = ((C->fy * q.y + C->cy * q.z) / zs) / ds;
-    const int cc = (int)fminf(fmaxf(rintf(u), 0.0f), (float)(C->hints.grid_w - 1));
-    const int cr = (int)fminf(fmaxf(rintf(v), 0.0f), (float)(C->hints.grid_h - 1));
-    return cr * C->hints.grid_w + cc;
+    const float ds = (float)k.ds;
+    const float u = ((k.fx * q.x + k.cx * q.z) / zs) / ds, v = ((k.fy * q.y + k.cy * q.z) / zs) / ds;
+    const int cc = (int)fminf(fmaxf(rintf(u), 0.0f), (float)(k.Wd - 1));
+    const int cr = (int)fminf(fmaxf(rintf(v), 0.0f), (float)(k.Hd - 1));
+    return cr * k.Wd + cc;
 }
 // GEOMETRIC PROOF.  Squared lower bound on the distance from s to every target OUTSIDE the (2R+1)^2 grid pixels around
 // `centre`.  A target sits in grid pixel (r, c) iff its projection (u, v) rounds to the image pixel (r ds, c ds), so
@@ -1265,28 +1274,29 @@ __device__ __forceinline__ int cam_cell(const LoopConst *C, const f3 p) {
 // half-space it is not in is the distance to its plane; the minimum over the (up to four) sides that can hold targets
 // at all -- beyond the image border there are none -- bounds the distance to every outside target from below.  Rigid
 // transforms preserve distances, so the bound is evaluated in camera coordinates.  Margins: 0.52 instead of 0.5 px,
-// 0.1 % + 10 um off the bound: orders of magnitude above fp32 rounding of the terms.  0 = no proof.
-__device__ __forceinline__ float cam_bound2(const LoopConst *C, const f3 s, const int centre, const int R) {
-    const f3 q = cam_point(C, s);
-    const int Wd = C->hints.grid_w, Hd = C->hints.grid_h;
-    const int cr = centre / Wd, cc = centre - cr * Wd;
-    const float ds = (float)C->hints.ds;
+// 0.2 % + 10 um off the bound (the plane normals are normalised with the hardware's 1-ulp reciprocal square root):
+// orders of magnitude above fp32 rounding of the terms.  0 = no proof.
+__device__ __forceinline__ float cam_bound2(const CamK &k, const f3 s, const int centre, const int R) {
+    const f3 q = cam_point(k, s);
+    const int cr = centre / k.Wd, cc = centre - cr * k.Wd;
+    const float ds = (float)k.ds;
     const float hw = (float)(R + 1) * ds - 0.52f;
     const float uc = (float)cc * ds, vc = (float)cr * ds;
     float L = INFINITY;
-    if (cc + R + 1 < Wd) { const float a = C->cx - (uc + hw); L = fminf(L, -(C->fx * q.x + a * q.z) / sqrtf(C->fx * C->fx + a * a)); }
-    if (cc - R - 1 >= 0) { const float a = C->cx - (uc - hw); L = fminf(L, (C->fx * q.x + a * q.z) / sqrtf(C->fx * C->fx + a * a)); }
-    if (cr + R + 1 < Hd) { const float a = C->cy - (vc + hw); L = fminf(L, -(C->fy * q.y + a * q.z) / sqrtf(C->fy * C->fy + a * a)); }
-    if (cr - R - 1 >= 0) { const float a = C->cy - (vc - hw); L = fminf(L, (C->fy * q.y + a * q.z) / sqrtf(C->fy * C->fy + a * a)); }
-    L = L * 0.999f - 1e-5f;
+    if (cc + R + 1 < k.Wd) { const float a = k.cx - (uc + hw); L = fminf(L, -(k.fx * q.x + a * q.z) * __builtin_amdgcn_rsqf(k.fx * k.fx + a * a)); }
+    if (cc - R - 1 >= 0) { const float a = k.cx - (uc - hw); L = fminf(L, (k.fx * q.x + a * q.z) * __builtin_amdgcn_rsqf(k.fx * k.fx + a * a)); }
+    if (cr + R + 1 < k.Hd) { const float a = k.cy - (vc + hw); L = fminf(L, -(k.fy * q.y + a * q.z) * __builtin_amdgcn_rsqf(k.fy * k.fy + a * a)); }
+    if (cr - R - 1 >= 0) { const float a = k.cy - (vc - hw); L = fminf(L, (k.fy * q.y + a * q.z) * __builtin_amdgcn_rsqf(k.fy * k.fy + a * a)); }
+    L = L * 0.998f - 1e-5f;
     return L > 0.0f ? L * L : 0.0f;  // (NaN compares false: no proof)
 }
 
 template <bool GRID>
 __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
                                                          const float *__restrict__ partials_in, int nblocks_in, int step_mode,
-                                                         int look_slot, float *__restrict__ rec, int first, int out_slot, LoopBufs B,
-                                                         float *__restrict__ partials /* gridDim.x x NACC */) {
+                                                         int look_slot, float *__restrict__ rec, int phase /* first | launch parity << 1 */,
+                                                         int out_slot, LoopBufs B, float *__restrict__ partials /* gridDim.x x NACC */) {
+    const int first = phase & 1, par = phase >> 1;
     __shared__ KnnShared sh;
     __shared__ IcpState st_sm;
     __shared__ float acc_sm[NACC];
@@ -1343,13 +1353,14 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         const int h = ok ? min(max(C->hints.src_pix[i], 0), nc - 1) : 0;
         // Window centre: the grid pixel the point projects to.  The point itself is only known once the step (wave 0,
         // concurrently) has produced dT -- but it is within millimetres of the cloud the PREVIOUS launch wrote, whatever
-        // the step decides (first launch: the caller's cloud under the initial transform, exactly).  The centre only
-        // selects which window is examined; the proof below is evaluated for the point's actual position against it.
+        // the step decides, and that launch left the pixel of every point it wrote in C->cells (by launch parity: one
+        // load at an address known at kernel start; first launch: the caller's cloud under the initial transform,
+        // exactly).  The centre only selects which window is examined; the proof below is evaluated for the point's
+        // actual position against it.
         int c = h;
-        if (ok && C->cam_ok) {
-            const f3 pp = first ? xform(S_in->dT, ld3(C->user_src, i)) : ld3(B.P(look_slot >= 0 ? look_slot : 1 - S_in->p_cur), i);
-            c = cam_cell(C, pp);
-        }
+        if (ok && C->cam_ok)
+            c = first ? cam_cell(C->cam, xform(S_in->dT, ld3(C->user_src, i)))
+                      : min(max(C->cells[(1 - par) * C->cells_stride + i], 0), nc - 1);
         float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
             int sj[2];
@@ -1388,6 +1399,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             if (2 * __popcll(m) >= __popcll(okm)) break;
             pool &= ~m;
         }
+        GS_STAMP(13);
         const bool mine = ok && ((sup >> lane) & 1);
         const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i(mine ? dsp : 0x7fffffff));
         const int e = mine ? dsp - dmin : 0;
@@ -1429,6 +1441,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         // the nearest neighbour is millimetres away and 3 x 3 (a third of the candidates) proves it.
         const bool sparse = (int64_t)nt < (int64_t)C->grid_r2_below_per_pixel * nc;
         if (C->grid_radius_max < 2 || WROWS < 5 || !sparse || !lay_bands(2)) { R = 1; lay_bands(1); }
+        GS_STAMP(14);
         // staging loads first (they are the long ones), the per-lane rows behind them
         constexpr int ST = KNN_BT - 64, NR = (POOL + ST - 1) / ST;
         float4 sreg[NR];
@@ -1469,6 +1482,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             }
             sh.wflag[lane] = min(rel, 2) | (full ? 4 : 0) | (R << 3);
             sh.centre[lane] = c;
+            if (lane < (int)(sizeof(CamK) / 4)) reinterpret_cast<int *>(&sh.cam)[lane] = reinterpret_cast<const int *>(&C->cam)[lane];
             sh.key[lane] = KEY_NONE;
             if (lane == 0) { sh.cnt = 0; sh.band[2 * WBANDS] = used; }
             if (lane < WBANDS) {
@@ -1485,6 +1499,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             const int e = (int)threadIdx.x - 64 + ST * r;
             if (e < used) *reinterpret_cast<float4 *>(&sh.u.stage[4 * e]) = sreg[r];
         }
+        GS_STAMP(15);
     }
     __syncthreads();
     if (step_mode >= 0 && blockIdx.x == 0 && threadIdx.x < kWords) {
@@ -1562,7 +1577,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         key_unpack(sh.key[lane], bd, bi);
         // proof: every target outside the window is at least sqrt(cam_bound2) away (see there); the window was examined
         // completely (rel & 4), so a best strictly inside the bound IS the nearest neighbour, tie-break included
-        const float bound2 = (ok && C->cam_ok) ? cam_bound2(C, s, sh.centre[lane], rel >> 3) : 0.0f;
+        const float bound2 = (ok && C->cam_ok) ? cam_bound2(sh.cam, s, sh.centre[lane], rel >> 3) : 0.0f;
         const bool proven = !C->cert_off & ((rel & 4) != 0) & (bd * 1.0001f < bound2);
         need = ok & !proven;
         const unsigned long long need_mask = __ballot(need);  // the same 64 lanes in every wave: block-uniform
@@ -1603,6 +1618,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     // reduced through LDS by the whole block in a fixed order (two short stages instead of 29 butterflies)
     if (wave == 0) {
         if (ok) best[i] = key;
+        if (grid && ok && C->cam_ok) C->cells[par * C->cells_stride + i] = cam_cell(sh.cam, s);  // where the next launch looks
         float acc[NACC];
 #pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -1668,9 +1684,10 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
         if (threadIdx.x == 0 && lc.hints.cam_pose && lc.hints.cam_K && lc.hints.ds > 0) {
             const float *T = lc.hints.cam_pose, *K = lc.hints.cam_K;
             const Cam c = make_cam(T, K);
-            for (int q = 0; q < 9; ++q) lc_out->camR[q] = c.R[q];
-            for (int q = 0; q < 3; ++q) lc_out->camT[q] = c.tinv[q];
-            lc_out->fx = K[0]; lc_out->fy = K[5]; lc_out->cx = K[2]; lc_out->cy = K[6];
+            for (int q = 0; q < 9; ++q) lc_out->cam.R[q] = c.R[q];
+            for (int q = 0; q < 3; ++q) lc_out->cam.T[q] = c.tinv[q];
+            lc_out->cam.fx = K[0]; lc_out->cam.fy = K[5]; lc_out->cam.cx = K[2]; lc_out->cam.cy = K[6];
+            lc_out->cam.ds = lc.hints.ds; lc_out->cam.Wd = lc.hints.grid_w; lc_out->cam.Hd = lc.hints.grid_h;
             // project_point divides (K row 0 / 1) . [x y z 1] by (K row 2) . [x y z 1]: the proof's planes assume the
             // plain pinhole form u = fx x / z + cx, v = fy y / z + cy
             const bool pinhole = K[1] == 0.0f && K[3] == 0.0f && K[4] == 0.0f && K[7] == 0.0f && K[8] == 0.0f && K[9] == 0.0f &&
@@ -1815,6 +1832,7 @@ struct IcpWs {
     float *partials[2];
     float *boxes, *sboxes;  // chunk boxes, and one box per SUPER chunks
     LoopConst *lc;       // the loop's constants (knn1_loop_k reads them from here, not from its arguments)
+    int32_t *cells;      // grid search: (2, max_ns) ds-grid pixel of every point an association wrote, by launch parity
 };
 static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out) {
     size_t off = 0;
@@ -1824,7 +1842,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
     const size_t oPart = take((size_t)loop_blocks_max(max_ns) * NACC * 4), oPart1 = take((size_t)loop_blocks_max(max_ns) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt)), oSBox = take((size_t)cdiv(max_nt > 0 ? max_nt : 1, 1024) * 6 * 4);
-    const size_t oLc = take(sizeof(LoopConst));
+    const size_t oLc = take(sizeof(LoopConst)), oCells = take((size_t)max_ns * 8);
     if (ws && out) {
         char *p = (char *)ws;
         out->S[0] = (IcpState *)(p + oS); out->S[1] = (IcpState *)(p + oS1);
@@ -1836,6 +1854,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
         out->boxes = (float *)(p + oBox);
         out->sboxes = (float *)(p + oSBox);
         out->lc = (LoopConst *)(p + oLc);
+        out->cells = (int32_t *)(p + oCells);
     }
     return off;
 }
@@ -1930,7 +1949,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
                              (g_grid_mode == 2 || dense);
     LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax, grid_r2_below,
                  0, 0, cert_off, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
-                 guard_min, (int)kgrid.x, grid_search ? 1 : 0, {0}, {0}, 0.0f, 0.0f, 0.0f, 0.0f, 0};
+                 guard_min, (int)kgrid.x, grid_search ? 1 : 0, CamK{}, 0, w.cells, max_ns};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
@@ -1958,11 +1977,11 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         float *rec_p = (tape && pending >= 0) ? tp.rec + (size_t)n_step * REC_WORDS : nullptr;
         if (grid_search)
             hipLaunchKernelGGL(knn1_loop_k<true>, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
-                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first, tape ? n_assoc : -1, w.B,
+                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
                                w.partials[nxt]);
         else
             hipLaunchKernelGGL(knn1_loop_k<false>, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
-                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first, tape ? n_assoc : -1, w.B,
+                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
                                w.partials[nxt]);
         prof_mark(0, 1, st);
         if (pending >= 0) ++n_step;

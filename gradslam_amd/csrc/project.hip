@@ -77,27 +77,31 @@ struct ActivePredL {
     __device__ void block_init(int /*pass*/) const {
         for (int b = threadIdx.x; b < B; b += blockDim.x) cam_cache()[b] = make_cam(poses + 16 * b, Ks + 16 * b);
     }
-    __device__ bool operator()(int64_t i) const {
+    struct Item { f3 p; };
+    __device__ Item fetch(int64_t i) const { return Item{ld3(points, i)}; }
+    __device__ bool test(const Item &it, int64_t i) const {
         const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
         if (n >= counts[b]) return false;
         int h, w;
-        if (!project_point(cam_cache()[b], ld3(points, i), H, W, umax, vmax, h, w)) return false;
+        if (!project_point(cam_cache()[b], it.p, H, W, umax, vmax, h, w)) return false;
         return ds <= 0 || ((h % ds == 0) && (w % ds == 0));
     }
+    __device__ bool operator()(int64_t i) const { return test(fetch(i), i); }
 };
 struct ActiveWriterL {
     const float *points;
     int64_t *rows;
     int Nmax, H, W;
     float umax, vmax;
-    __device__ void operator()(int64_t i, int64_t pos) const {
+    __device__ void put(const ActivePredL::Item &it, int64_t i, int64_t pos) const {
         const int b = (int)(i / Nmax), n = (int)(i - (int64_t)b * Nmax);
         int h, w;
-        project_point(cam_cache()[b], ld3(points, i), H, W, umax, vmax, h, w);
+        project_point(cam_cache()[b], it.p, H, W, umax, vmax, h, w);
         longlong4 r;  // one 32-byte store per row
         r.x = b; r.y = n; r.z = h; r.w = w;
         *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
     }
+    __device__ void operator()(int64_t i, int64_t pos) const { put(ActivePredL::Item{ld3(points, i)}, i, pos); }
 };
 
 // The same projection for ONE sequence when its result feeds the ICP target build: the count pass also zeroes
@@ -116,12 +120,15 @@ struct ActivePredH {
         if (pass == 0)
             for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) { cnt[i] = 0; fill[i] = 0; }
     }
-    __device__ bool operator()(int64_t i) const {
+    struct Item { f3 p; };
+    __device__ Item fetch(int64_t i) const { return Item{ld3(points, i)}; }
+    __device__ bool test(const Item &it, int64_t i) const {
         if (i >= counts[0]) return false;
         int h, w;
-        if (!project_point(cam_cache()[0], ld3(points, i), H, W, umax, vmax, h, w)) return false;
+        if (!project_point(cam_cache()[0], it.p, H, W, umax, vmax, h, w)) return false;
         return (h % ds == 0) && (w % ds == 0);
     }
+    __device__ bool operator()(int64_t i) const { return test(fetch(i), i); }
 };
 struct ActiveWriterH {
     const float *points;
@@ -129,14 +136,15 @@ struct ActiveWriterH {
     int H, W, ds, Wd;
     float umax, vmax;
     int *cnt;
-    __device__ void operator()(int64_t i, int64_t pos) const {
+    __device__ void put(const ActivePredH::Item &it, int64_t i, int64_t pos) const {
         int h, w;
-        project_point(cam_cache()[0], ld3(points, i), H, W, umax, vmax, h, w);
+        project_point(cam_cache()[0], it.p, H, W, umax, vmax, h, w);
         longlong4 r;
         r.x = 0; r.y = i; r.z = h; r.w = w;
         *reinterpret_cast<longlong4 *>(rows + 4 * pos) = r;
         atomicAdd(cnt + (h / ds) * Wd + (w / ds), 1);
     }
+    __device__ void operator()(int64_t i, int64_t pos) const { put(ActivePredH::Item{ld3(points, i)}, i, pos); }
 };
 
 // starts[b] = first table row with row.b >= b (rows sorted by b); starts[B] = n_rows

@@ -49,6 +49,11 @@ t0, t1, t2, t3, ns, t6, t7 = a[..., 0], a[..., 1], a[..., 2], a[..., 3], a[..., 
 pc = lambda x, q: tuple(np.percentile(x, q))
 print("prologue (folded step) us per wave p50 %.2f p99 %.2f" % pc((t7 - t6) * tick, [50, 99]))
 print("prologue end -> search start p50 %.2f" % np.percentile((t0 - t7) * tick, 50))
+w0, ws = a[:, 0, :], a[:, 1:, :]  # wave 0 = the folded step; waves 1.. = the staging path of the grid search
+if (ws[..., 15] > 0).any():
+    rel = lambda slot: (ws[..., slot] - ws[..., 6]) * tick
+    print("staging waves, us after kernel entry (p50): centre + tile displacement known %.2f | bands laid out %.2f | staged to LDS %.2f | barrier passed %.2f ; wave 0 (step) reaches the barrier at %.2f"
+          % (np.percentile(rel(13), 50), np.percentile(rel(14), 50), np.percentile(rel(15), 50), np.percentile(rel(7), 50), np.percentile((w0[..., 7] - w0[..., 6]) * tick, 50)))
 print("seed phase us  (per wave)  p50 %.2f p99 %.2f" % pc((t1 - t0) * tick, [50, 99]))
 print("main loop us   (per wave)  p50 %.2f p99 %.2f max %.2f" % pc((t2 - t1) * tick, [50, 99, 100]))
 print("barrier wait us(per wave)  p50 %.2f p99 %.2f" % pc((t3 - t2) * tick, [50, 99]))

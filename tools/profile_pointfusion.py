@@ -13,7 +13,9 @@ dev = "cuda:0"
 c, d, K, P = make_sequence(1, n, 480, 640, seed=100)
 frames = gs.RGBDImages(c.to(dev), d.to(dev), K.to(dev), P.to(dev))
 slam = gs.slam.PointFusion(odom=odom, dsratio=4, numiters=10, device=dev)
-with torch.no_grad():
+import contextlib
+side = torch.cuda.stream(torch.cuda.Stream()) if os.environ.get("GS_SIDE_STREAM") else contextlib.nullcontext()
+with torch.no_grad(), side:
     slam(gs.RGBDImages(c[:, :3].to(dev), d[:, :3].to(dev), K.to(dev), P[:, :3].to(dev)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
