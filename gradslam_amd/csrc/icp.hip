@@ -56,7 +56,6 @@ constexpr int NACC = 29;        // 21 (upper H) + 6 (g) + e + count
 constexpr int LIN_T = 256;
 constexpr int LIN_MAXB = 1024;  // max partial blocks of the stand-alone J kernel (best of 512/1024/2048 measured at 2^24 points)
 constexpr unsigned long long KEY_NONE = ~0ull;
-constexpr int GRID_MIN_PER_PIXEL = 4;  // grid search from this many targets per ds-grid pixel (average) on
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int j) {
     return ((unsigned long long)fbits(d) << 32) | (unsigned int)j;
@@ -1223,21 +1222,13 @@ struct LoopConst {
     const float *user_src, *tgt, *nrm, *boxes, *sboxes;
     const int32_t *d_ns, *d_nt;
     float *trace, *out_T;
-    const int32_t *guard_count;  // small tiles only if ALSO *guard_count >= guard_min (the map's actual size; NULL: no such guard)
     gs_icp_hints hints;
     GradParams gp;
     float thresh;
-    int grid_min_per_pixel;
-    int grid_radius_max;   // largest window radius tried (2 or 1)
-    int grid_r2_below_per_pixel;  // radius 2 while the target holds fewer than this many points per ds-grid pixel
     int ns, nt;            // *d_ns, *d_nt as icp_prepare_k found them (one dependent load less at every kernel start)
     int cert_off;          // measurements only (GS_CERT_OFF=1): never trust a proof -> every association searches exactly
-    int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each).  The host
-                           // hands in the size for a DENSE target (loop_tile_points); icp_prepare_k replaces it by 64 when
-                           // the target's actual count says sparse -- a decision made from device-side counts only
-    int dense_min_per_pixel;  // ... dense = at least this many targets per ds-grid pixel on average (0: whatever the count)
-    int guard_min;
-    int loop_blocks;          // blocks of every association launch of this loop (the small tiles must cover the cloud)
+    int tile_points;       // source points per block (lanes 0 .. tile_points - 1 of every wave hold one each): 64, or what
+                           // gs_set_tile_points forces (tests)
     int grid_variant;         // this loop launches knn1_loop_k<true> (for the loop counters only)
     // the camera the targets were bucketed with (hints.cam_pose / cam_K as icp_prepare_k read them): world -> camera as
     // project_point (gs_project.hpp) applies it, and the pinhole constants.  cam_ok = 0: K is not a plain pinhole
@@ -1309,19 +1300,37 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     const int i = tile0 + lane;
     const bool ok = lane < C->tile_points && i < ns;
     const bool tile_live = tile0 < ns && nt > 0;
-    // The launch holds enough blocks for the smallest tile size; on a sparse target (64-point tiles) the surplus ones
-    // leave at once.  Their partial rows are zeros at the END of every thread's summation sequence in reduce_partials:
-    // the sums are bit for bit those of a launch without them.  (Block 0 publishes the state: it always stays.)
+    // The launch covers the cloud's CAPACITY; blocks beyond its actual size leave at once.  Their partial rows are zeros at
+    // the END of every thread's summation sequence in reduce_partials (not even read).  (Block 0 publishes the state: it
+    // always stays.)
     if (tile0 >= ns && blockIdx.x != 0) {
         if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
         return;
     }
-    // The grid search pays where pixels hold several targets (a map that has seen many frames): chunk C->boxes are
-    // compact there and neighbour distances small against the pixel pitch, so certificates hold from the second
-    // association on.  On a sparse target (about one per pixel: C->boxes 16 pixels long, neighbours half a pixel away)
-    // they rarely do before the loop has converged, and the chunk-box search alone is faster.
-    const bool grid = GRID && (int64_t)nt >= (int64_t)C->grid_min_per_pixel * C->hints.grid_w * C->hints.grid_h;
+    constexpr bool grid = GRID;  // (the host launches this variant only with complete hints and camera)
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
+    // GRID: what the staging waves need first -- the lane's own pixel, the pixel its point projects to (previous launch's
+    // cells / the caller's cloud), wave 1's seed keys and its copy of the camera constants -- is REQUESTED here, before the
+    // partial rows of the folded step: every trip to memory at kernel start costs ~2 us (the data was written by other
+    // XCDs' CUs), and these then share one trip with the rows instead of following it (phase stamps, r03h: the centre was
+    // known 4.1 us after kernel entry, the barrier behind the staging fell at 10.7 us)
+    int e_h = 0, e_c = -1, e_cam = 0;
+    f3 e_pp{0.0f, 0.0f, 0.0f};
+    unsigned long long e_ka = 0, e_kb = 0;
+    if (GRID && grid && tile_live && wave != 0) {
+        if (ok) {
+            e_h = C->hints.src_pix[i];
+            if (C->cam_ok) {
+                if (first) e_pp = ld3(C->user_src, i);
+                else e_c = C->cells[(1 - par) * C->cells_stride + i];
+            }
+            if (wave == 1 && !first) {
+                const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
+                e_ka = B.N(ba)[i]; e_kb = B.N(bb)[i];
+            }
+        }
+        if (wave == 1 && lane < (int)(sizeof(CamK) / 4)) e_cam = reinterpret_cast<const int *>(&C->cam)[lane];
+    }
 
     // ---- the O(1) step is wave 0's; GRID: the other fifteen waves meanwhile work out the window of every lane and the
     // row bands of the tile, stage the bands' targets into LDS and fetch the seed for either outcome of the step.
@@ -1350,7 +1359,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         }
     } else if (grid && tile_live) {
         const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
-        const int h = ok ? min(max(C->hints.src_pix[i], 0), nc - 1) : 0;
+        const int h = ok ? min(max(e_h, 0), nc - 1) : 0;
         // Window centre: the grid pixel the point projects to.  The point itself is only known once the step (wave 0,
         // concurrently) has produced dT -- but it is within millimetres of the cloud the PREVIOUS launch wrote, whatever
         // the step decides, and that launch left the pixel of every point it wrote in C->cells (by launch parity: one
@@ -1358,9 +1367,20 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         // exactly).  The centre only selects which window is examined; the proof below is evaluated for the point's
         // actual position against it.
         int c = h;
-        if (ok && C->cam_ok)
-            c = first ? cam_cell(C->cam, xform(S_in->dT, ld3(C->user_src, i)))
-                      : min(max(C->cells[(1 - par) * C->cells_stride + i], 0), nc - 1);
+        if (ok && C->cam_ok) c = first ? cam_cell(C->cam, xform(S_in->dT, e_pp)) : min(max(e_c, 0), nc - 1);
+        // wave 1: the first / one-past-last slots of the lane's three window rows -- requested as soon as the centre is known,
+        // ahead of the tile's reductions and band loads (they used to leave last and the block's barrier waited for them)
+        int row_lo[WROWS], row_hi[WROWS];
+#pragma unroll
+        for (int r = 0; r < WROWS; ++r) { row_lo[r] = 0; row_hi[r] = 0; }
+        if (wave == 1) {
+#pragma unroll
+            for (int r = 0; r < WROWS; ++r) {
+                const int g = c + (r - 1) * Wd;
+                row_lo[r] = C->hints.pix_start[min(max(g - 1, 0), nc - 1)];
+                row_hi[r] = C->hints.pix_start[min(max(g + 1, 0), nc - 1) + 1];
+            }
+        }
         float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
             int sj[2];
@@ -1368,11 +1388,9 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 const int slot = min(max(C->hints.pix_start[h], 0), nt - 1);
                 sj[0] = sj[1] = min(max(C->hints.scan_orig[slot], 0), nt - 1);
             } else {
-                const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
-                const unsigned long long ka = B.N(ba)[i], kb = B.N(bb)[i];
                 // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
-                sj[0] = (int)min((uint32_t)(ka & 0xffffffffu), (uint32_t)(nt - 1));
-                sj[1] = (int)min((uint32_t)(kb & 0xffffffffu), (uint32_t)(nt - 1));
+                sj[0] = (int)min((uint32_t)(e_ka & 0xffffffffu), (uint32_t)(nt - 1));
+                sj[1] = (int)min((uint32_t)(e_kb & 0xffffffffu), (uint32_t)(nt - 1));
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1410,37 +1428,35 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         const int bmin = __builtin_amdgcn_readfirstlane(wave_min_i(in ? beta : 0x7fffffff));
         const int bmax = __builtin_amdgcn_readfirstlane(wave_max_i(in ? beta : (int)0x80000000));
         const bool two_rows = __any(in && rel == 1);
-        auto slot_lo = [&](int cell) { return min(max(C->hints.pix_start[cell], 0), nt) & ~(CHUNK - 1); };
-        auto slot_hi = [&](int cell) { return min((min(max(C->hints.pix_start[cell + 1], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt); };
-        // Window radius: 2 (5 x 5 pixels) while the bands of the tile fit the pool -- a sparse target, where the
-        // wider window is what gives the certificate its margin -- else 1 (3 x 3).  Band kk covers the pixels
-        // [bmin + (kk - R) Wd - R, bmax + (kk - R) Wd + R], kk = 0 .. 2 R (+ 1 if the lanes sit in two rows).
-        int bbase[WBANDS], boff[WBANDS], bcnt[WBANDS], used = 0, R = 2;
-        auto lay_bands = [&](int rad) {
-            used = 0;
-            bool fits = true;
+        // Band kk covers the pixels [bmin + (kk - R) Wd - R, bmax + (kk - R) Wd + R], kk = 0 .. 2 R (+ 1 if the lanes sit in
+        // two rows), R = 1 (radius 2 = five rows, six bands was measured: ~1 us per launch more on a dense target, nothing
+        // gained on a sparse one).  All first-slot loads are issued before any is used: taken one band after the other
+        // they were four dependent trips through the scalar cache (2.4 us, r03h).
+        constexpr int R = 1;
+        int bbase[WBANDS], boff[WBANDS], bcnt[WBANDS], used = 0;
+        {
+            int lo_raw[WBANDS], hi_raw[WBANDS];
+            bool want[WBANDS];
+#pragma unroll
+            for (int kk = 0; kk < WBANDS; ++kk) {
+                const int a = bmin + (kk - R) * Wd - R, b = bmax + (kk - R) * Wd + R;
+                want[kk] = kk <= 2 * R + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1;
+                lo_raw[kk] = C->hints.pix_start[min(max(a, 0), nc - 1)];
+                hi_raw[kk] = C->hints.pix_start[min(max(b, 0), nc - 1) + 1];
+            }
 #pragma unroll
             for (int kk = 0; kk < WBANDS; ++kk) {
                 bbase[kk] = 0; bcnt[kk] = 0; boff[kk] = used;
-                const int a = bmin + (kk - rad) * Wd - rad, b = bmax + (kk - rad) * Wd + rad;
-                if (kk <= 2 * rad + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1) {
-                    const int lo = slot_lo(max(a, 0)), hi = slot_hi(min(b, nc - 1));
-                    if (hi > lo) {
-                        bbase[kk] = lo; bcnt[kk] = hi - lo;
-                        // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
-                        // window stays complete and with it the certificate): pool offset -1
-                        if (used + (hi - lo) <= POOL) used += hi - lo; else { boff[kk] = -1; fits = false; }
-                    }
+                const int lo = min(max(lo_raw[kk], 0), nt) & ~(CHUNK - 1);
+                const int hi = min((min(max(hi_raw[kk], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt);
+                if (want[kk] && hi > lo) {
+                    bbase[kk] = lo; bcnt[kk] = hi - lo;
+                    // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
+                    // window stays complete and with it the proof): pool offset -1
+                    if (used + (hi - lo) <= POOL) used += hi - lo; else boff[kk] = -1;
                 }
             }
-            return fits;
-        };
-        // Radius 2 (5 x 5 pixels) on a SPARSE target: with about one target per pixel the nearest one may be the
-        // neighbouring pixel's (a hole, a depth edge) and the 3 x 3 window's bound (~5 pixel pitches of the image) is then
-        // too tight; the 5 x 5 window bounds everything outside by ~9.5 pitches and costs 25 candidates.  On a dense target
-        // the nearest neighbour is millimetres away and 3 x 3 (a third of the candidates) proves it.
-        const bool sparse = (int64_t)nt < (int64_t)C->grid_r2_below_per_pixel * nc;
-        if (C->grid_radius_max < 2 || WROWS < 5 || !sparse || !lay_bands(2)) { R = 1; lay_bands(1); }
+        }
         GS_STAMP(14);
         // staging loads first (they are the long ones), the per-lane rows behind them
         constexpr int ST = KNN_BT - 64, NR = (POOL + ST - 1) / ST;
@@ -1467,7 +1483,8 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 int packed = 0;
                 const int g = c + (r - R) * Wd;
                 if (in && r <= 2 * R && g + R >= 0 && g - R <= nc - 1) {
-                    const int lo = slot_lo(max(g - R, 0)), hi = slot_hi(min(g + R, nc - 1));
+                    const int lo = min(max(row_lo[r], 0), nt) & ~(CHUNK - 1);
+                    const int hi = min((min(max(row_hi[r], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt);
                     if (hi > lo) {
                         int bb = bbase[0], bn = bcnt[0];
 #pragma unroll
@@ -1482,7 +1499,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             }
             sh.wflag[lane] = min(rel, 2) | (full ? 4 : 0) | (R << 3);
             sh.centre[lane] = c;
-            if (lane < (int)(sizeof(CamK) / 4)) reinterpret_cast<int *>(&sh.cam)[lane] = reinterpret_cast<const int *>(&C->cam)[lane];
+            if (lane < (int)(sizeof(CamK) / 4)) reinterpret_cast<int *>(&sh.cam)[lane] = e_cam;
             sh.key[lane] = KEY_NONE;
             if (lane == 0) { sh.cnt = 0; sh.band[2 * WBANDS] = used; }
             if (lane < WBANDS) {
@@ -1667,15 +1684,10 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
         int v = reinterpret_cast<const int *>(&lc)[threadIdx.x];
         if (threadIdx.x == offsetof(LoopConst, ns) / 4) v = *lc.d_ns;
         if (threadIdx.x == offsetof(LoopConst, nt) / 4) v = *lc.d_nt;
-        if (threadIdx.x == offsetof(LoopConst, tile_points) / 4) {
-            const int64_t pixels = (int64_t)lc.hints.grid_w * lc.hints.grid_h;
-            const bool dense = lc.dense_min_per_pixel == 0 || (pixels > 0 && (int64_t)*lc.d_nt >= lc.dense_min_per_pixel * pixels);
-            const bool guard = lc.guard_count == nullptr || *lc.guard_count >= lc.guard_min;
-            const bool covers = (int64_t)lc.loop_blocks * lc.tile_points >= (int64_t)*lc.d_ns;  // (by construction; never relied on)
-            v = (dense && guard && covers) ? lc.tile_points : 64;
+        if (threadIdx.x == offsetof(LoopConst, tile_points) / 4) {  // (any one thread: the loop counters of gs_loop_counts)
             atomicAdd(&g_loop_counts[0], 1u);
-            if (v != 64) atomicAdd(&g_loop_counts[2], 1u);
-            if (lc.grid_variant && pixels > 0 && (int64_t)*lc.d_nt >= (int64_t)lc.grid_min_per_pixel * pixels) atomicAdd(&g_loop_counts[1], 1u);
+            if (lc.grid_variant) atomicAdd(&g_loop_counts[1], 1u);
+            if (lc.tile_points != 64) atomicAdd(&g_loop_counts[2], 1u);
         }
         reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
     }
@@ -1800,28 +1812,18 @@ bool profiling_enabled() { return g_prof.on; }
 static int g_grid_mode = getenv("GS_GRID_MODE") ? atoi(getenv("GS_GRID_MODE")) : 1;  // gs_set_grid_search (environment: measurements)
 static int g_tile_points = 0;  // gs_set_tile_points (0 = automatic)
 
-// Source points per block of the loops' association kernel (knn1_loop_k).  A 1024-thread block is one co-residency
-// unit: a CU holds two.  With 64-point tiles a 160 x 120 ds-grid is ~290 blocks on 256 CUs -- some CUs host two
-// full-rate blocks, most host one, and on a dense target (search-bound launches, VALU-issue bound) the launch lasts as
-// long as the doubled ones.  Between one and two blocks per CU the tile shrinks instead, so that EVERY CU hosts two
-// smaller tiles: the same block, lanes tile_points .. 63 idle, fewer surviving chunk boxes per tile.  Measured
-// (MI355X, 160 x 120 ds-grid): 38-point tiles give 1 248 against 1 178 frames/s over 200 frames; on the sparse
-// single-frame target of the c2 step (latency-bound launches) they cost 20.7 us per launch against 18.8 -- so the
-// small tiles are for dense targets only.
-// The tile size fixes the order of the 29-term sums (per tile, then over tiles), so it must be a function of the
-// DATA: the host launches enough blocks for the small tiles whenever max_ns is in the range, and icp_prepare_k picks
-// 64 or the small size from the target's actual count on the device (LoopConst::tile_points).  The host's own idea of
-// the density (an upper bound of the map size that depends on when asynchronous read-backs land) only selects the
-// search variant, which never changes a bit of the result.
+// Source points per block of the loops' association kernel (knn1_loop_k): 64 -- lane = point.  Round 2 cut a dense
+// target's cloud into 38-point tiles (every CU two equal tiles: the chunk-box search there was VALU-issue bound and a
+// launch lasted as long as its doubled-up CUs); with the grid search's geometric proof the launch is latency-bound at every
+// density and the tile size no longer matters (200 frames, MI355X: 1 864 / 1 842 / 1 838 frames/s for 64 / the round-2 rule /
+// 38, profiles/r03d), so the rule is gone and with it the surplus blocks it launched while a map grew dense.  The
+// setting remains for tests (gs_set_tile_points): the tile size fixes the order of the 29-term sums, so results of
+// different settings agree to rounding, nearest neighbours exactly.
 constexpr int TILE_MIN = 32;
-static inline int loop_tile_points(int max_ns, bool have_grid, bool *forced_out) {
+static inline int loop_tile_points() {
     static const int env = getenv("GS_TILE_POINTS") ? atoi(getenv("GS_TILE_POINTS")) : 0;
     const int forced = g_tile_points ? g_tile_points : env;
-    *forced_out = forced >= TILE_MIN && forced <= 64;
-    if (*forced_out) return forced;
-    const int b64 = cdiv(max_ns, 64);
-    if (!have_grid || b64 <= 256 || b64 > 2 * 256) return 64;
-    return max(TILE_MIN, cdiv(max_ns, 2 * 256));
+    return (forced >= TILE_MIN && forced <= 64) ? forced : 64;
 }
 int icp_config_stamp() { return g_grid_mode | (g_tile_points << 4); }  // part of slam.hip's graph-cache key
 static inline int loop_blocks_max(int max_ns) { return cdiv(max_ns, TILE_MIN); }  // workspace: whatever the tile size
@@ -1888,9 +1890,7 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
                    const int32_t *d_nt, int max_nt, const float *init_T, int numiters, float damp, float thresh,
                    GradParams gp, const gs_icp_hints *hints_in, float *out_T, uint64_t *best_last, float *trace, void *ws,
                    size_t ws_bytes, hipStream_t st, const char *name, void *tape = nullptr, size_t tape_bytes = 0,
-                   const float *compose_right = nullptr, float *compose_out = nullptr,
-                   int dense_hint = -1 /* caller's knowledge of the target's density: 1 dense, 0 sparse, -1 judge by max_nt */,
-                   const int32_t *guard_count = nullptr, int guard_min = 0 /* see LoopConst::guard_count */) {
+                   const float *compose_right = nullptr, float *compose_out = nullptr) {
     gs_icp_hints hints{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
     if (hints_in) hints = *hints_in;
     GS_REQUIRE(!hints.scan_points || hints.scan_orig, "%s: hints.scan_points needs hints.scan_orig", name);
@@ -1921,35 +1921,20 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         w.B = tp.B;  // the tape is the loop's working storage
     }
     int n_assoc = 0, n_step = 0;
-    static const int grid_min_env = getenv("GS_GRID_MIN_PER_PIXEL") ? atoi(getenv("GS_GRID_MIN_PER_PIXEL")) : GRID_MIN_PER_PIXEL;
-    // dense target (several points per ds-grid pixel: a map that has seen many frames), by the caller's word or by size
-    const bool dense = hints.grid_w > 0 && hints.grid_h > 0 && dense_hint != 0 &&
-                       (dense_hint > 0 || (int64_t)max_nt >= (int64_t)grid_min_env * hints.grid_w * hints.grid_h);
-    bool tile_forced = false;
-    // A caller that hands in the map's count (gs_slam_localize) promises dense_hint != 0 whenever that count reaches
-    // guard_min (its bound Nmax is never below the count): only then can the device choose the small tiles, so a launch
-    // whose bound says "cannot be dense" (the c2 step on a one-frame map) carries no surplus blocks.
-    const bool small_geometry = hints.grid_w > 0 && hints.grid_h > 0 && (guard_count == nullptr || dense_hint != 0);
-    const int tile_points = loop_tile_points(max_ns, small_geometry, &tile_forced);
-    const dim3 kgrid(cdiv(max_ns, tile_points));  // enough for the small tiles; on a sparse target the surplus blocks leave at once
+    const int tile_points = loop_tile_points();
+    const dim3 kgrid(cdiv(max_ns, tile_points));
     const int lb = (int)kgrid.x;  // one partial row per tile, written by the association kernel
     const int fb = min(cdiv(max_ns, 256), 256);
 
-    const int grid_min = g_grid_mode == 2 ? 0 : grid_min_env;  // mode 2: whatever the density (tests)
-    static const int grid_rmax = getenv("GS_GRID_RADIUS") ? atoi(getenv("GS_GRID_RADIUS")) : 2;
-    static const int grid_r2_below = getenv("GS_GRID_R2_BELOW") ? atoi(getenv("GS_GRID_R2_BELOW")) : 3;
     static const int cert_off = getenv("GS_CERT_OFF") != nullptr;
-    // all hints given: grid search with distance certificates (knn1_loop_k<true>); GS_NO_GRID_SEARCH=1 keeps the
-    // chunk-box search for every association (same results; for A/B measurements and tests)
+    // all hints and the camera given: grid search with its geometric proof (knn1_loop_k<true>), at every density;
+    // GS_NO_GRID_SEARCH=1 / gs_set_grid_search(0) keep the chunk-box search for every association (same results; for
+    // A/B measurements and tests)
     static const bool grid_off = getenv("GS_NO_GRID_SEARCH") != nullptr;
-    // ... and only where the target can be dense enough for it (the kernel checks the actual count again): the grid
-    // variant carries more registers and 32 bytes of scratch, 1.4 us per launch on a sparse target
     const bool grid_search = !grid_off && g_grid_mode != 0 && hints.scan_points && hints.scan_orig && hints.src_pix && hints.pix_start &&
-                             hints.cam_pose && hints.cam_K && hints.ds > 0 && hints.grid_w > 0 && hints.grid_h > 0 &&
-                             (g_grid_mode == 2 || dense);
-    LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, tile_forced ? nullptr : guard_count, hints, gp, thresh, grid_min, grid_rmax, grid_r2_below,
-                 0, 0, cert_off, tile_points, (tile_forced || tile_points == 64) ? 0 : grid_min_env,
-                 guard_min, (int)kgrid.x, grid_search ? 1 : 0, CamK{}, 0, w.cells, max_ns};
+                             hints.cam_pose && hints.cam_K && hints.ds > 0 && hints.grid_w > 0 && hints.grid_h > 0;
+    LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, hints, gp, thresh, 0, 0, cert_off, tile_points,
+                 grid_search ? 1 : 0, CamK{}, 0, w.cells, max_ns};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
                        hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
     GS_LAUNCH_CHECK(name);
@@ -2453,13 +2438,12 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
 int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                      const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
                      float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
-                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint,
-                     const int32_t *guard_count, int guard_min) {
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out) {
     const GradParams gp = grad_lm ? GradParams{(float)(1.0 / (double)lambda_max), (float)((double)lambda_max - 1.0 / (double)lambda_max),
                                                Bp, B2, (float)(1.0 / (double)nu)}
                                   : GradParams{0.5f, 1.5f, 1.0f, 1.0f, 0.005f};
     return icp_run(grad_lm != 0, src, d_ns, max_ns, tgt, nrm, d_nt, max_nt, nullptr, numiters, damp, thresh, gp, hints, out_T, nullptr,
-                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out, dense_hint, guard_count, guard_min);
+                   nullptr, ws, ws_bytes, st, "gs_slam_localize/icp", tape, tape_bytes, compose_right, compose_out);
 }
 
 }  // namespace gs
@@ -2478,8 +2462,8 @@ void gs_set_grid_search(int on) { g_grid_mode = on; }
 void gs_set_tile_points(int n) { g_tile_points = n; }
 int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_points_dense, int *partial_rows) {
     GS_REQUIRE(max_ns > 0, "gs_icp_launch_geometry: max_ns must be positive");
-    bool forced = false;
-    const int tp = loop_tile_points(max_ns, have_hints != 0, &forced);
+    (void)have_hints;
+    const int tp = loop_tile_points();
     if (blocks) *blocks = cdiv(max_ns, tp);
     if (tile_points_dense) *tile_points_dense = tp;
     if (partial_rows) *partial_rows = loop_blocks_max(max_ns);

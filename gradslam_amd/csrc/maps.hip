@@ -52,6 +52,8 @@ struct VnExtra {
     unsigned int *pix_n;           // (B*L*H*W) or NULL: set to ~0
     int32_t *zero;                 // n_zero words zeroed by the first block, or NULL
     int n_zero;
+    float *cam_out;                // (B*L, 32) or NULL: a copy of every frame's pose | intrinsics at an address of the CALLEE's
+                                   // choosing (gs_slam_localize: its workspace -- what a captured graph of the ICP loops may bake in)
 };
 
 __global__ __launch_bounds__(TW *TH) void vertex_normal_k(const float *__restrict__ depth, const float *__restrict__ Ks,
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(TW *TH) void vertex_normal_k(const float *__restric
     __shared__ float sd[TH + 1][TW + 1];
     if (ex.zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         for (int i = threadIdx.x; i < ex.n_zero; i += TW * TH) ex.zero[i] = 0;
+    if (ex.cam_out && poses && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 32) {
+        const int blz = blockIdx.z;
+        ex.cam_out[32 * blz + threadIdx.x] = threadIdx.x < 16 ? poses[16 * (int64_t)blz + threadIdx.x] : Ks[16 * (blz / L) + threadIdx.x - 16];
+    }
     const int bl = blockIdx.z;  // b*L + l
     const int b = bl / L;
     const int w0 = blockIdx.x * TW, h0 = blockIdx.y * TH;
@@ -495,7 +501,7 @@ int gs_vertex_normal_maps(const float *depth, const float *intrinsics, const flo
     GS_REQUIRE((int64_t)B * L <= 65535, "gs_vertex_normal_maps: B*L must be <= 65535");
     dim3 grid(cdiv(W, TW), cdiv(H, TH), B * L);
     hipLaunchKernelGGL(vertex_normal_k, grid, dim3(TW * TH), 0, (hipStream_t)stream, depth, intrinsics, poses, L, H, W,
-                       vertex, normal, gvertex, gnormal, VnExtra{nullptr, 1.0f, 0.0f, nullptr, nullptr, nullptr, 0});
+                       vertex, normal, gvertex, gnormal, VnExtra{nullptr, 1.0f, 0.0f, nullptr, nullptr, nullptr, 0, nullptr});
     GS_LAUNCH_CHECK("gs_vertex_normal_maps");
     return GS_OK;
 }
@@ -510,8 +516,17 @@ int vertex_normal_maps_fusion(const float *depth, const float *intrinsics, const
                               int32_t *zero, int n_zero, hipStream_t st) {
     dim3 grid(cdiv(W, TW), cdiv(H, TH), B);
     hipLaunchKernelGGL(vertex_normal_k, grid, dim3(TW * TH), 0, st, depth, intrinsics, poses, 1, H, W, (float *)nullptr,
-                       (float *)nullptr, gvertex, gnormal, VnExtra{alpha, 2.0f * (sigma * sigma), eps, pix_key, pix_n, zero, n_zero});
+                       (float *)nullptr, gvertex, gnormal, VnExtra{alpha, 2.0f * (sigma * sigma), eps, pix_key, pix_n, zero, n_zero, nullptr});
     GS_LAUNCH_CHECK("gs_pointfusion_update/maps");
+    return GS_OK;
+}
+// the maps of gs_slam_localize (one frame per batch element) + a copy of (pose | intrinsics) per batch element at cam_out
+int vertex_normal_maps_cam(const float *depth, const float *intrinsics, const float *poses, int B, int H, int W, float *vertex,
+                           float *normal, float *gvertex, float *gnormal, float *cam_out, hipStream_t st) {
+    dim3 grid(cdiv(W, TW), cdiv(H, TH), B);
+    hipLaunchKernelGGL(vertex_normal_k, grid, dim3(TW * TH), 0, st, depth, intrinsics, poses, 1, H, W, vertex, normal, gvertex, gnormal,
+                       VnExtra{nullptr, 1.0f, 0.0f, nullptr, nullptr, nullptr, 0, cam_out});
+    GS_LAUNCH_CHECK("gs_slam_localize/maps");
     return GS_OK;
 }
 }  // namespace gs

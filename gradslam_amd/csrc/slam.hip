@@ -22,13 +22,12 @@ struct GraphKey {
     void *ws;
     int B, capS, capT, numiters, use_grad;
     float damp, thresh, lmax, Bp, B2, nu;
-    int dense, icp_cfg;  // what else decides WHICH kernels a loop launches: the density hint, gs_set_grid_search / _tile_points
-    const void *map_counts;  // the one caller-owned address a loop reads (the map's counts: LoopConst::guard_count, icp.hip)
-    int H, W, ds;            // the loop's constants hold the ds-grid's dimensions and the map-size guard derived from them
+    int icp_cfg;             // what else decides WHICH kernels a loop launches: gs_set_grid_search / gs_set_tile_points
+    int H, W, ds;            // the loop's constants hold the ds-grid's dimensions
     bool operator==(const GraphKey &o) const {
         return H == o.H && W == o.W && ds == o.ds && ws == o.ws && B == o.B && capS == o.capS && capT == o.capT && numiters == o.numiters && use_grad == o.use_grad &&
-               damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu && dense == o.dense &&
-               icp_cfg == o.icp_cfg && map_counts == o.map_counts;
+               damp == o.damp && thresh == o.thresh && lmax == o.lmax && Bp == o.Bp && B2 == o.B2 && nu == o.nu &&
+               icp_cfg == o.icp_cfg;
     }
 };
 struct GraphEntry {
@@ -75,16 +74,11 @@ __global__ void compose_k(const float *__restrict__ T, const float *__restrict__
 int icp_localize_run(int grad_lm, const float *src, const int32_t *d_ns, int max_ns, const float *tgt, const float *nrm,
                      const int32_t *d_nt, int max_nt, int numiters, float damp, float thresh, float lambda_max, float Bp,
                      float B2, float nu, const gs_icp_hints *hints, float *out_T, void *ws, size_t ws_bytes, hipStream_t st,
-                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out, int dense_hint,
-                     const int32_t *guard_count, int guard_min);
+                     void *tape, size_t tape_bytes, const float *compose_right, float *compose_out);
 int icp_config_stamp();  // icp.hip: the process-wide search / tiling switches, as one number
-// the ICP target holds about Nmax / ds^2 of the map's points: dense (several per ds-grid pixel) once the map has
-// seen a few frames -- what selects the grid search (icp.hip)
-static inline int dense_map_points(int H, int W, int ds) {  // map size from which the target can hold 4 points per ds-grid pixel
-    return (int)std::min<int64_t>(4LL * ds * ds * cdiv(H, ds) * cdiv(W, ds), 0x7fffffff);
-}
-static inline int target_dense(int Nmax, int H, int W, int ds) { return Nmax >= dense_map_points(H, W, ds) ? 1 : 0; }
-
+// maps.hip: the maps of one frame per batch element + (pose | intrinsics) copied to cam_out (B, 32)
+int vertex_normal_maps_cam(const float *depth, const float *intrinsics, const float *poses, int B, int H, int W, float *vertex,
+                           float *normal, float *gvertex, float *gnormal, float *cam_out, hipStream_t st);
 __global__ void eye4_k(float *__restrict__ T, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 16 * B) T[i] = ((i % 16) % 5 == 0) ? 1.0f : 0.0f;
@@ -111,6 +105,7 @@ struct LocWs {
     int32_t *nt;       // (B)
     float *T;          // (B, 16) ICP result; eye (B,16) follows
     float *eye;
+    float *cam;        // (B, 32) previous pose | intrinsics: the bucketing camera at a workspace address (graph replay)
     void *sub;         // scratch shared by the sub-calls (they run one after the other on one stream)
     size_t sub_bytes;
 };
@@ -135,7 +130,7 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     // into a captured graph stay valid while the map grows inside one capacity bucket
     const size_t o_rows = take((size_t)B * capT * 32), o_nrows = take(4);
     const size_t o_tgt = take((size_t)B * capT * 12), o_tnrm = take((size_t)B * capT * 12), o_nt = take((size_t)B * 4);
-    const size_t o_T = take((size_t)B * 64), o_eye = take((size_t)B * 64);
+    const size_t o_T = take((size_t)B * 64), o_eye = take((size_t)B * 64), o_cam = take((size_t)B * 128);
     size_t sub = gs_downsample_frame_ws_bytes(H, W, ds);
     sub = std::max(sub, gs_project_active_ws_bytes(B, Nmax));
     sub = std::max(sub, gs_gather_table_rows_ws_bytes(B));
@@ -151,7 +146,7 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
         out->tgt_pix = (int32_t *)(p + o_tpix);
         out->rows = (int64_t *)(p + o_rows); out->nrows = (int32_t *)(p + o_nrows);
         out->tgt = (float *)(p + o_tgt); out->tnrm = (float *)(p + o_tnrm); out->nt = (int32_t *)(p + o_nt);
-        out->T = (float *)(p + o_T); out->eye = (float *)(p + o_eye);
+        out->T = (float *)(p + o_T); out->eye = (float *)(p + o_eye); out->cam = (float *)(p + o_cam);
         out->sub = p + o_sub; out->sub_bytes = sub;
     }
     return off;
@@ -357,7 +352,9 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
     int rc;
     // live frame posed with the previous pose: maps, then the ds-grid source cloud
-    if ((rc = gs_vertex_normal_maps(depth, intrinsics, prev_poses, B, 1, H, W, vertex, normal, gvertex, gnormal, stream))) return rc;
+    // (the maps kernel also leaves the bucketing camera -- previous pose and intrinsics -- in the workspace: the loops read it
+    // from there, an address a captured graph may keep, never from the caller's tensors)
+    if ((rc = vertex_normal_maps_cam(depth, intrinsics, prev_poses, B, H, W, vertex, normal, gvertex, gnormal, w.cam, st))) return rc;
     if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.src_pix, w.ns,
                                   w.sub, w.sub_bytes, stream))) return rc;
     // map points that land on the ds-grid of the previous frame: the ICP target
@@ -374,21 +371,18 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     }
     // fold_compose: the loop's last launch also writes out_poses = T . prev_poses.  Only for eager launches: a
     // captured graph must not bake the caller's prev_poses / out_poses addresses in (they change every call).
-    // (map_counts IS baked in -- the loop's first launch reads the map's size from it -- and is part of the graph's key:
-    // a sequence driver keeps its counts in one device tensor for the whole sequence.)
     auto enqueue_loops = [&](gs_stream_t s, bool fold_compose) -> int {
         for (int b = 0; b < B; ++b) {  // sequences are independent; one device-resident loop each
             const float *src = w.src + (size_t)b * capS * 3;
             const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
             const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
                                      w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds),
-                                     prev_poses + 16 * b, intrinsics + 16 * b, ds};
+                                     w.cam + 32 * b, w.cam + 32 * b + 16, ds};
             // the loop's last launch also writes out_poses[b] = T . prev_poses[b]
             const int r = icp_localize_run(use_grad_lm, src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, numiters, damp, dist_thresh,
                                            lambda_max, Bp, B2, nu, &hints, w.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)s, nullptr,
                                            0, fold_compose ? prev_poses + 16 * b : nullptr,
-                                           fold_compose ? out_poses + 16 * b : nullptr, target_dense(Nmax, H, W, ds),
-                                           map_counts + b, dense_map_points(H, W, ds));
+                                           fold_compose ? out_poses + 16 * b : nullptr);
             if (r) return r;
         }
         return GS_OK;
@@ -399,7 +393,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
         int device = 0;
         (void)hipGetDevice(&device);
         const GraphKey key{ws, B, capS, capT, numiters, use_grad_lm, damp, dist_thresh, lambda_max, Bp, B2, nu,
-                           target_dense(Nmax, H, W, ds), icp_config_stamp(), map_counts, H, W, ds};
+                           icp_config_stamp(), H, W, ds};
         GraphEntry *hit = nullptr;
         for (auto &e : g_graphs)
             if (e.device == device && e.key == key) hit = &e;
@@ -665,8 +659,7 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
         if ((rc = icp_localize_run(use_grad_lm, tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
                                    w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, numiters, damp, dist_thresh, lambda_max, Bp, B2, nu,
                                    &hints, tp.T + 16 * b, w.sub, w.sub_bytes, (hipStream_t)stream, tp.icp + (size_t)b * tp.icp_bytes,
-                                   tp.icp_bytes, prev_poses + 16 * b, out_poses + 16 * b, target_dense(Nmax, H, W, ds),
-                                   map_counts + b, dense_map_points(H, W, ds))))
+                                   tp.icp_bytes, prev_poses + 16 * b, out_poses + 16 * b)))
             return rc;
     }
     if (numiters == 0) return gs_compose_poses(tp.T, prev_poses, B, out_poses, stream);

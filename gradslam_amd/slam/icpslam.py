@@ -17,6 +17,11 @@ from .fusionutils import _project, update_map_aggregate
 __all__ = ["ICPSLAM"]
 
 
+import os as _os
+
+_NO_READBACK = bool(_os.environ.get("GS_NO_READBACK"))  # measurements only: never tighten the host's bound of the map size
+
+
 class _MapArena:
     """Device-resident map storage for the streamed sequence driver: capacity-doubling
     (B, cap, C) arrays, per-sequence point counts that live on the device, O(1) append.  The host only tracks an
@@ -95,7 +100,7 @@ class _MapArena:
     def appended(self):
         self.upper += self.hw
         self.appends += 1
-        if self._pinned:
+        if self._pinned and not _NO_READBACK:
             buf = self._pinned.pop()
             buf.copy_(self.counts, non_blocking=True)
             ev = torch.cuda.Event()

@@ -396,31 +396,24 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
 void gs_profile_enable(int on);
 int gs_profile_read(int tag, long *launches, double *total_ms);
 
-/* How the loops above associate when ALL gs_icp_hints are given.  1 (default) = automatic: grid search with per-point
- * distance certificates (see gs_icp_hints) where the target holds several points per ds-grid pixel (a map that has
- * seen many frames), the chunk-box search otherwise; 2 = grid search whatever the density; 0 = chunk-box search
- * always.  Same results bit for bit (all are the brute-force scan's); only the cost differs.  Replaces nothing in the
+/* How the loops above associate when ALL gs_icp_hints (camera included) are given.  1 (default; 2 is accepted as the
+ * same) = grid search with its geometric proof (see gs_icp_hints), at every target density; 0 = chunk-box search always.
+ * Same results bit for bit (both are the brute-force scan's); only the cost differs.  Replaces nothing in the
  * reference (chamferdist.knn_points has no such switch); for measurements and tests. */
 void gs_set_grid_search(int on);
 
-/* Source points per 1024-thread block of the loops' association kernel: 0 (default) = automatic -- 64, or
- * ceil(max_ns / 512) where max_ns lies between 16 385 and 32 768, search hints are given and the target holds at
- * least four points per ds-grid pixel (decided on the device from the target's count -- inside gs_slam_localize
- * also from the map's: at least 4 H W points -- so the choice is a function of the data: every CU then hosts two
- * equal tiles instead of some CUs two and most one); 32 .. 64 = that many, whatever the density.  The tile size fixes the summation order of the 6x6 system, so results of different
- * settings agree to rounding, not bit for bit; nearest neighbours are the brute-force scan's under every setting.
- * Replaces nothing in the reference; for measurements and tests. */
+/* Source points per 1024-thread block of the loops' association kernel: 0 (default) = 64; 32 .. 64 = that many (tests:
+ * the tile size fixes the summation order of the 6x6 system, so results of different settings agree to rounding, not bit
+ * for bit; nearest neighbours are the brute-force scan's under every setting).  Replaces nothing in the reference. */
 void gs_set_tile_points(int n);
 /* Launch geometry of one association launch of the loops above for a source capacity (host-side query, no device
- * work): blocks launched, source points per block on a dense target, and the number of partial rows the workspace
- * (gs_icp_ws_bytes) holds per buffer (>= blocks for every tile-size setting). */
+ * work): blocks launched, source points per block, and the number of partial rows the workspace (gs_icp_ws_bytes)
+ * holds per buffer (>= blocks for every tile-size setting).  have_hints is ignored since ABI 3. */
 int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_points_dense, int *partial_rows);
-/* What the DEVICE decided for the loops run so far (each loop's prepare kernel adds to four counters from the counts it
- * finds on the device): out4 = {loops, loops associated by grid search (variant launched and the target's actual count
- * at least four per ds-grid pixel), loops cut into small tiles, tiles whose point-serial straggler search overflowed
- * its pair list and was redone by the tile-level search}.  Synchronises with the device; reset != 0 zeroes
- * the counters afterwards.  Replaces nothing in the reference; lets a test assert that a long sequence really ran the
- * dense-target paths. */
+/* Counters kept on the DEVICE for the loops run so far: out4 = {loops, loops associated by grid search, loops with a
+ * forced tile size (gs_set_tile_points), tiles whose point-serial straggler search overflowed its pair list and was
+ * redone by the tile-level search}.  Synchronises with the device; reset != 0 zeroes the counters afterwards.  Replaces
+ * nothing in the reference; lets a test assert which paths a run really exercised. */
 int gs_loop_counts(unsigned int *out4, int reset);
 
 /* ---------------------------------------------------------------- C+U: fusion correspondences

@@ -33,9 +33,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_icp_launch_geometry_fits_the_workspace():
-    """The loops' association launch (host-side rule, no device work): 64-point tiles, or -- with search hints, between
-    one and two 64-point blocks per CU -- enough blocks for tiles small enough that 512 of them cover the cloud; the
-    workspace holds a partial row for every block under every tile-size setting."""
+    """The loops' association launch (host-side rule, no device work): 64-point tiles unless a test forces another size;
+    the workspace holds a partial row for every block under every tile-size setting."""
     import ctypes
 
     lib = _native.lib()
@@ -45,12 +44,10 @@ def test_icp_launch_geometry_fits_the_workspace():
         assert lib.gs_icp_launch_geometry(max_ns, hints, ctypes.byref(b), ctypes.byref(t), ctypes.byref(r)) == 0
         return b.value, t.value, r.value
 
-    assert geom(19200, 1) == (506, 38, 600)          # 160 x 120 ds-grid: every CU two equal tiles
-    assert geom(19200, 0)[:2] == (300, 64)            # no hints: no density to go by
-    assert geom(16384, 1)[:2] == (256, 64)            # one block per CU already
-    assert geom(16385, 1)[:2] == (497, 33)
-    assert geom(32768, 1)[:2] == (512, 64)
-    assert geom(78408, 1)[:2] == (1226, 64)           # more blocks than the chip holds: 64-point tiles, unfolded steps
+    assert geom(19200, 1) == (300, 64, 600)          # 160 x 120 ds-grid
+    assert geom(19200, 0)[:2] == (300, 64)
+    assert geom(16385, 1)[:2] == (257, 64)
+    assert geom(78408, 1)[:2] == (1226, 64)           # more blocks than the chip holds: unfolded steps
     try:
         for forced in (0, 32, 47, 64):
             lib.gs_set_tile_points(forced)
