@@ -78,6 +78,21 @@ def vertex_normal_maps_backward_raw(depth, K, poses, gV_l=None, gN_l=None, gV_g=
     return g_depth, g_K, g_P
 
 
+def vertex_normal_maps_backward_into(depth, K, poses, gV_l, gN_l, gV_g, gN_g, g_depth, g_K, g_poses):
+    """vertex_normal_maps_backward_raw that ADDS into caller-held adjoints (contiguous float32, same shapes as depth / K /
+    poses; the C kernels accumulate into all three): what a reverse pass over many frames wants -- no temporaries, no
+    zero fills, no `+=` launches per frame."""
+    depth_c, K_c, poses_c = _f32c(depth), _f32c(K), _f32c(poses)
+    B, L, H, W = depth_c.shape[:4]
+    for x in (g_depth, g_K, g_poses):
+        if x is not None and not (x.is_contiguous() and x.dtype == torch.float32):
+            raise ValueError("vertex_normal_maps_backward_into: the adjoint buffers must be contiguous float32")
+    gV_l, gN_l, gV_g, gN_g = _f32c(gV_l), _f32c(gN_l), _f32c(gV_g), _f32c(gN_g)
+    ws = workspace(ws_bytes("gs_vertex_normal_maps_backward_ws_bytes", B, L, H, W), depth_c.device, "maps_bwd")
+    call("gs_vertex_normal_maps_backward", ptr(depth_c), ptr(K_c), ptr(poses_c), B, L, H, W, ptr(gV_l), ptr(gN_l),
+         ptr(gV_g), ptr(gN_g), ptr(g_depth), ptr(g_K), ptr(g_poses), ptr(ws), ws.numel(), stream())
+
+
 def vertex_normal_maps(depth, K, poses, want_local=True, want_global=True):
     """Autograd-aware entry: returns (V, N, gV, gN) (None where not requested)."""
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (depth, K, poses))
@@ -691,34 +706,31 @@ class _PointFusionSeqFn(torch.autograd.Function):
         g_rgb, g_depth, g_K = torch.zeros_like(rgb), torch.zeros_like(depth), torch.zeros_like(K)
         g_poses_in = torch.zeros((B, L, 4, 4), dtype=torch.float32, device=dev) if ctx.has_poses else None
         mk = lambda c: torch.empty((B, H, W, c), dtype=torch.float32, device=dev)
-        g_V, g_gV, g_gN, g_c_s = mk(3), mk(3), mk(3), mk(3)
+        g_V, g_gV, g_gN = mk(3), mk(3), mk(3)
+        g_live = torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev)
+        g_prev = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+        # One sequence (B = 1): the per-frame slices of the adjoints are contiguous, so every kernel writes or ADDS straight
+        # into them -- no per-frame temporaries, zero fills or `+=` launches (a dozen small torch kernels per frame, and
+        # their host cost, in the first version of this loop).
         for s in reversed(range(L)):
-            d_s, c_s = depth[:, s].contiguous(), rgb[:, s].contiguous()
-            pose_s = recovered[:, s:s + 1].contiguous()
+            d_s, c_s = depth[:, s], rgb[:, s]
+            pose_s = recovered[:, s:s + 1]
             ftape, bound = frames[s]["fuse"]
             ws = workspace(ws_bytes("gs_pointfusion_update_backward_ws_bytes", B, H, W), dev, "fusion_bwd")
             call("gs_pointfusion_update_backward", ptr(d_s), ptr(c_s), ptr(K), ptr(pose_s), B, H, W, ptr(mp), ptr(mn), ptr(mc), ptr(mf),
                  ptr(counts), bound, sigma, ptr(ftape), ftape.numel(), ptr(Gp), ptr(Gn), ptr(Gc), ptr(Gf), ptr(g_V), ptr(g_gV),
-                 ptr(g_gN), ptr(g_c_s), ptr(ws), ws.numel(), stream())
-            g_rgb[:, s] = g_c_s.view_as(g_rgb[:, s])
-            gd, gk, gP = vertex_normal_maps_backward_raw(d_s.unsqueeze(1), K, pose_s, g_V.unsqueeze(1), None, g_gV.unsqueeze(1),
-                                                         g_gN.unsqueeze(1))
-            g_depth[:, s] += gd.view_as(g_depth[:, s])
-            g_K += gk.view_as(g_K)
-            gpose[:, s] += gP.view(B, 4, 4)
+                 ptr(g_gN), ptr(g_rgb[:, s]), ptr(ws), ws.numel(), stream())
+            vertex_normal_maps_backward_into(d_s.unsqueeze(1), K, pose_s, g_V.unsqueeze(1), None, g_gV.unsqueeze(1), g_gN.unsqueeze(1),
+                                             g_depth[:, s], g_K, gpose[:, s])
             if "loc" in frames[s]:
                 tape, nmax = frames[s]["loc"]
-                prev = recovered[:, s - 1:s].contiguous()
-                g_live = torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev)
-                g_prev = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+                prev = recovered[:, s - 1:s]
                 ws = workspace(ws_bytes("gs_slam_localize_backward_ws_bytes", B, H, W, ds, nmax), dev, "localize_bwd")
                 call("gs_slam_localize_backward", ptr(prev), B, H, W, ds, ptr(mp), ptr(mn), nmax, grad_lm, numiters, thresh, lmax, Bp, B2,
-                     nu, ptr(tape), tape.numel(), ptr(gpose[:, s:s + 1].contiguous()), ptr(g_live), ptr(Gp), ptr(Gn), ptr(g_prev), 1,
+                     nu, ptr(tape), tape.numel(), ptr(gpose[:, s:s + 1]), ptr(g_live), ptr(Gp), ptr(Gn), ptr(g_prev), 1,
                      ptr(ws), ws.numel(), stream())
-                gd, gk, gP = vertex_normal_maps_backward_raw(d_s.unsqueeze(1), K, prev, None, None, g_live, None)
-                g_depth[:, s] += gd.view_as(g_depth[:, s])
-                g_K += gk.view_as(g_K)
-                gpose[:, s - 1] += gP.view(B, 4, 4) + g_prev.view(B, 4, 4)
+                vertex_normal_maps_backward_into(d_s.unsqueeze(1), K, prev, None, None, g_live, None, g_depth[:, s], g_K, gpose[:, s - 1])
+                gpose[:, s - 1] += g_prev.view(B, 4, 4)
             elif g_poses_in is not None:
                 g_poses_in[:, s] += gpose[:, s]
         return g_rgb, g_depth, g_K, g_poses_in, None

@@ -62,9 +62,20 @@ class _MapArena:
         self.upper, self.appends, self._pinned, self._pending = n_old, 0, [], []
         return self
 
+    # The host may run at most this many frames ahead of the map counts it knows.  The row bound it hands to the kernels
+    # and the capacity it reserves are `last known count + frames since x H W`: a host that enqueues four times faster than
+    # the GPU executes (0.13 against 0.4-0.6 ms per frame on the round-3 boxes) would otherwise be ~150 frames ahead by
+    # the end of a 200-frame sequence, none of its read-backs would have landed when it needs them, and the arena would be
+    # grown -- allocated, zero-filled, copied -- as if every frame had appended H W points (46 M rows instead of 3.3 M:
+    # the 200-frame forward ran at 1 600 frames/s where the same kernels with exact bounds run at 2 650, and FASTER under
+    # rocprofv3, whose per-launch host cost happens to keep the host near the GPU: tools/gap_bisect.py).  Two frames of
+    # queued work (~1 ms) keep the GPU fed on any host.
+    MAX_FRAMES_AHEAD = 2
+
     def _tighten(self):
-        while self._pending and self._pending[0][2].query():
-            at, buf, _ = self._pending.pop(0)
+        while self._pending and (self._pending[0][2].query() or self.appends - self._pending[0][0] >= self.MAX_FRAMES_AHEAD):
+            at, buf, ev = self._pending.pop(0)
+            ev.synchronize()  # (returns at once when the query above succeeded)
             self._pinned.append(buf)
             self.upper = min(self.upper, int(buf.max()) + (self.appends - at) * self.hw)
 

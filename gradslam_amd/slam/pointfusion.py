@@ -65,7 +65,33 @@ class PointFusion(ICPSLAM):
             return False
         if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)):
             return False  # nothing to differentiate: the streamed / step-by-step drivers
-        return frames.shape[0] == 1 and frames.shape[2] >= 2 and frames.shape[3] >= 2
+        if not (frames.shape[0] == 1 and frames.shape[2] >= 2 and frames.shape[3] >= 2):
+            return False
+        # Memory law of the sequence node: it keeps, until backward, one fusion tape (44 B per pixel) and one localisation
+        # tape (the ICP loop's clouds and neighbour arrays, ~20 B per ds-grid point and association, + 4 B per target slot)
+        # per frame, and the arena -- ~7.7 GB for 200 frames of 640x480.  A sequence whose tapes would not fit takes the
+        # per-frame nodes instead (slower, but every frame's intermediates are freed as autograd walks back).
+        need = self.sequence_tape_bytes(frames.shape[1], frames.shape[2], frames.shape[3])
+        free = torch.cuda.mem_get_info(frames.device)[0]
+        if need > 0.8 * free:
+            warnings.warn("PointFusion: the one-node differentiable sequence would keep ~{:.1f} GB of tapes ({:.1f} GB free): "
+                          "taking one autograd node per frame instead".format(need / 1e9, free / 1e9))
+            return False
+        return True
+
+    def sequence_tape_bytes(self, L: int, H: int, W: int) -> int:
+        """Projected bytes the one-node differentiable sequence keeps until backward (see _can_fuse_sequence): exact in the
+        per-pixel and per-iteration terms, with the map's growth taken as 5 % of a frame per frame (what the synthetic and
+        the reference's fixture sequences show; the target-slot term is the only one that depends on it)."""
+        p = self.odomprov
+        iters = p.numiters if p is not None else 0
+        ds = max(int(self.dsratio), 1)
+        src = -(-H // ds) * -(-W // ds)
+        assoc = (2 * iters if self.odom == "gradicp" else iters + 1) if self.odom != "gt" else 0
+        map_pts = int((1.0 + 0.05 * L) * H * W)
+        cap_t = 1 << max(map_pts - 1, 1).bit_length()
+        per_frame = 44 * H * W + assoc * 20 * src + 16 * src + (4 * cap_t if assoc else 0)
+        return L * per_frame + 2 * 40 * map_pts  # + the arena and its copy in backward
 
     def _forward_sequence_node(self, frames: RGBDImages):
         from .. import ops

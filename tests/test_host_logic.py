@@ -427,3 +427,18 @@ def test_require_hip_rejects_tensors_of_another_device(monkeypatch):
     _native.require_hip(_T(1), op="probe")
     with pytest.raises(RuntimeError, match="tensor is on cuda:0"):
         _native.require_hip(_T(0), op="probe")
+
+
+def test_sequence_tape_projection():
+    """PointFusion.sequence_tape_bytes: the memory law of the one-node differentiable sequence (44 B per pixel and frame for
+    the fusion tape, ~20 B per ds-grid point and association for the localisation tape, 4 B per target slot): the figure
+    measured at configs[2] (~7.7 GB for 200 frames of 640x480, gradicp) and its scaling."""
+    import gradslam_amd as gs
+
+    pf = gs.slam.PointFusion(odom="gradicp", dsratio=4, numiters=10)
+    full = pf.sequence_tape_bytes(200, 480, 640)
+    assert 6e9 < full < 10e9
+    assert pf.sequence_tape_bytes(100, 480, 640) < 0.6 * full
+    gt = gs.slam.PointFusion(odom="gt")
+    assert gt.sequence_tape_bytes(200, 480, 640) < 0.5 * full  # no localisation tape at all
+    assert gs.slam.PointFusion(odom="icp", dsratio=4, numiters=10).sequence_tape_bytes(200, 480, 640) < full
