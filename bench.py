@@ -106,19 +106,22 @@ def hbm_roofline_linearize(gs, dev, n_pts=1 << 24, reps=20):
     avg = sum(kept) / len(kept)
     alg = 40.0 * n_pts
     ach = alg / (avg * 1e-3) / 1e9
-    traffic = None
-    try:  # HBM bytes per launch from the PMC passes of this round (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pj = json.load(f)
-        if pj.get("n_points") == n_pts:
-            traffic = pj["linearize_k"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_file, traffic_commit = None, None, None
+    for name in ("r03_pmc_traffic.json", "r01_pmc_traffic.json"):  # HBM bytes per launch from the committed PMC passes (newest first)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pj = json.load(f)
+            if pj.get("n_points") == n_pts:
+                traffic, traffic_file, traffic_commit = pj["linearize_k"]["hbm_bytes_per_launch"], name, pj.get("commit", "round 1")
+                break
+        except Exception:
+            pass
     return {"kernel": "gs_icp_linearize = linearize_k + finalize44_k (J: gather associated target point + normal, "
                       "Jacobian row, 6x6 / 6 / 1 reduce)", "bound": "hbm", "achieved": round(ach, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_traffic.json: PMC passes of round 1 over this kernel at this size (FETCH_SIZE x2 "
-                              "gfx950 correction + WRITE_SIZE per launch) -- read from the committed profile, NOT measured in this run",
+            "traffic_source": "profiles/{}: separate --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel at this size (gfx950 FETCH "
+                              "correction calibrated on transform_k) taken at commit {} -- read from the committed profile, NOT measured "
+                              "in this run".format(traffic_file, traffic_commit),
             "n_points": n_pts,
             "bytes_per_point": 40, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg, 4), "launches": len(kept),
             "launches_discarded_as_preempted": len(ms) - len(kept),
@@ -305,8 +308,9 @@ def aux_fusion_update_roofline(gs, dev, n_frames=31):
     alg = 12.0 * n_map + 32.0 * n_act + 48.0 * n_act + 120.0 * n_uni + 52.0 * H * W
     return {"map_points": n_map, "active_rows": n_act, "unique_rows": n_uni, "call_ms": round(ms, 4), "algorithmic_bytes_per_frame": alg,
             "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg / (ms * 1e-3) / 8e12, 4),
-            "note": "one gs_pointfusion_update call (18 launches: maps, alpha, projection, similar, unique, in-place merge, append) on "
-                    "a map of {} points (capacity {}), median of 5 HIP-event timings; bytes by SURVEY.md 8(d)".format(n_map, cap)}
+            "note": "one gs_pointfusion_update call (7 launches: maps + alpha, table-free correspondence passes 1 / 2, in-place merge, "
+                    "append count / write, finish) on a map of {} points (capacity {}), median of 5 HIP-event timings; bytes by "
+                    "SURVEY.md 8(d), whose 32 B/row table and 48 B/row unique stage this chain no longer moves".format(n_map, cap)}
 
 
 def aux_c3_full_length(gs, dev, n_frames=200):
@@ -527,11 +531,14 @@ def main():
         ns = nt = (H // DS) * (W // DS)
         avg_knn_ms = ms_knn / max(n_knn, 1)
         valu = None
-        try:  # executed work of the same kernel on the same workload: counter passes of this round (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_knn1_loop_valu.json")) as f:
-                valu = json.load(f)
-        except Exception:
-            pass
+        for name in ("r03_pmc_knn1_loop_valu.json", "r02_pmc_knn1_loop_valu.json"):  # executed work of the same kernel on the same
+            try:                                                                      # workload: committed counter passes, newest first
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    valu = json.load(f)
+                valu["profile_file"] = name  # (each profile carries the commit it was taken at)
+                break
+            except Exception:
+                pass
         line = {
             "metric": "RGB-D frames/sec (640x480, 10 ICP iters)",
             "value": round(world * args.steps / dt, 3),
@@ -552,17 +559,17 @@ def main():
                        "parallelism": "one sequence per GPU, final RCCL all_gather of poses", "pose_max_abs_err": pose_err,
                        "timing": "median of {} timed regions of {} steps each".format(len(dts), args.steps)},
             "roofline_timed_region": {
-                "kernel": "knn1_loop_k (X+K+J fused: the previous iteration's O(1) step -- reduce, LM decision, 6x6 solve, exp -- "
-                          "on wave 0, then rigid transform, exact 1-NN association with fp32-exact AABB pruning, "
-                          "Jacobian rows and 29-term reduce of its 64-point tile -- 38-point tiles on a dense target of a long "
-                          "sequence, decided on the device from the target's and the map's counts)",
+                "kernel": "knn1_loop_k<true> (X+K+J fused: the previous iteration's O(1) step -- reduce, LM decision, 6x6 solve, exp -- "
+                          "on wave 0 while the other waves stage the windows; then rigid transform, exact 1-NN association by grid "
+                          "search with a geometric proof per point (exact chunk-box search for the points it fails for), "
+                          "Jacobian rows and 29-term reduce of its 64-point tile)",
                 "launches": n_knn, "avg_launch_ms": round(avg_knn_ms, 5),
                 "timing_source": "HIP events on the launch stream, second eager pass of {} steps".format(n_prof),
                 "hbm_view": {"algorithmic_bytes_per_launch": 40.0 * ns, "achieved_GBps": round(40.0 * ns / (avg_knn_ms * 1e-3) / 1e9, 2)
                              if n_knn else 0.0, "frac_of_8TBps": round(40.0 * ns / (avg_knn_ms * 1e-3) / 8e12, 5) if n_knn else 0.0,
                              "note": "0.77 MB per launch lives in L2: not an HBM measurement (fetched bytes per launch: "
                                      "profiles/r01t_pmc_knn1_loop.json)"},
-                "valu_view": valu if valu is not None else {"note": "profiles/r02_pmc_knn1_loop_valu.json not found"}},
+                "valu_view": valu if valu is not None else {"note": "no committed counter pass found under profiles/"}},
         }
         try:
             line["roofline"] = hbm_roofline_linearize(gs, dev)

@@ -37,7 +37,9 @@ names = {k: names[k] for k in keep}
 n = len(per)
 assert n, "no knn1_loop_k launch with grid %d in %s" % (grid, src)
 mean = lambda k: sum(d.get(k, 0.0) for d in per.values()) / n
-out = {"source": "rocprofv3 --pmc (one pass, with --kernel-trace only) over `python3 bench.py --no-cpu-baseline --steps 20 --warmup 3`, "
+import os
+out = {"commit": os.environ.get("GS_COMMIT", "unknown"),
+       "source": "rocprofv3 --pmc (one pass, with --kernel-trace only) over `python3 bench.py --no-cpu-baseline --steps 20 --warmup 3`, "
                  "MI355X; tools/pmc_knn_valu.py; read from this committed profile by bench.py, NOT measured in the bench run",
        "kernel": sorted(set(x.split("(")[0] for x in names.values())), "launches": n, "grid_work_items": grid}
 for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
