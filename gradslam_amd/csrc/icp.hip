@@ -2101,79 +2101,6 @@ __device__ __forceinline__ f3 rot_t(const float *R, const f3 g) {  // R^T g, R r
     return f3{R[0] * g.x + R[3] * g.y + R[6] * g.z, R[1] * g.x + R[4] * g.y + R[7] * g.z, R[2] * g.x + R[5] * g.y + R[8] * g.z};
 }
 
-// B (gradLM): adjoint of new_err = e(look, NN(look)); gP_i <- R2^T gP_i + R1^T glook_i ; sums glook (x) s
-__global__ __launch_bounds__(BWD_T) void bwd_look_k(const BwdState *__restrict__ Sb, LoopBufs B, const int32_t *__restrict__ d_ns,
-                                                    const float *__restrict__ tgt, const float *__restrict__ nrm, float thresh,
-                                                    float *__restrict__ gP, float *__restrict__ g_tgt, float *__restrict__ g_nrm,
-                                                    float *__restrict__ partials) {
-    __shared__ float G[44];
-    __shared__ float R[18];
-    if (threadIdx.x < 44) G[threadIdx.x] = (threadIdx.x == 42) ? Sb->g_new_err : 0.0f;
-    if (threadIdx.x >= 64 && threadIdx.x < 73) R[threadIdx.x - 64] = Sb->R2[threadIdx.x - 64];
-    if (threadIdx.x >= 128 && threadIdx.x < 137) R[9 + threadIdx.x - 128] = Sb->R1[threadIdx.x - 128];
-    __syncthreads();
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
-    const float *src = B.P(Sb->src_slot), *look = B.P(Sb->look_slot);
-    const unsigned long long *nn = B.N(Sb->look_slot);
-    const int ns = *d_ns;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
-        const Row r = make_row(look, tgt, nrm, nn, i, ns, thresh);
-        f3 gl{0.0f, 0.0f, 0.0f};
-        if (r.valid) gl = lin_point_bwd(G, r, ld3(look, i), (uint32_t)(nn[i] & 0xffffffffu), tgt, nrm, g_tgt, g_nrm);
-        acc_outer(acc, gl, ld3(src, i));
-        const f3 a = rot_t(R, ld3(gP, i)), b = rot_t(R + 9, gl);
-        st3(gP, i, f3{a.x + b.x, a.y + b.y, a.z + b.z});
-    }
-    block_store12(acc, partials);
-}
-
-// C: gP_i <- (rotate ? R2^T gP_i : gP_i) + adjoint of (H, g, e) at the iteration's source cloud; sums of
-// gP (x) predecessor cloud for the S kernel of the step that made this cloud
-__global__ __launch_bounds__(BWD_T) void bwd_lin_k(const BwdState *__restrict__ Sb, int rotate, LoopBufs B,
-                                                   const float *__restrict__ user_src,
-                                                   const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
-                                                   const float *__restrict__ nrm, float thresh, float *__restrict__ gP,
-                                                   float *__restrict__ g_tgt, float *__restrict__ g_nrm,
-                                                   float *__restrict__ partials) {
-    if (!Sb->active) return;  // rejected LM iteration: gP and the pending sums stay as they are
-    __shared__ float G[44];
-    __shared__ float R[9];
-    if (threadIdx.x < 44) G[threadIdx.x] = Sb->G[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 73) R[threadIdx.x - 64] = Sb->R2[threadIdx.x - 64];
-    __syncthreads();
-    const float *src = B.P(Sb->src_slot);
-    const float *prev = Sb->prev_slot >= 0 ? B.P(Sb->prev_slot) : user_src;
-    const unsigned long long *nn = B.N(Sb->nn_slot);
-    const int ns = *d_ns;
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
-        const Row r = make_row(src, tgt, nrm, nn, i, ns, thresh);
-        f3 g = ld3(gP, i);
-        if (rotate) g = rot_t(R, g);
-        if (r.valid) {
-            const f3 sb = lin_point_bwd(G, r, ld3(src, i), (uint32_t)(nn[i] & 0xffffffffu), tgt, nrm, g_tgt, g_nrm);
-            g.x += sb.x; g.y += sb.y; g.z += sb.z;
-        }
-        st3(gP, i, g);
-        acc_outer(acc, g, ld3(prev, i));
-    }
-    block_store12(acc, partials);
-}
-
-// last: through src0 = init_T . user_src
-__global__ __launch_bounds__(BWD_T) void bwd_finish_k(const float *__restrict__ init_T, const int32_t *__restrict__ d_ns,
-                                                      const float *__restrict__ gP, float *__restrict__ g_src) {
-    __shared__ float R[9];
-    if (threadIdx.x < 9) R[threadIdx.x] = init_T[4 * (threadIdx.x / 3) + threadIdx.x % 3];
-    __syncthreads();
-    const int ns = *d_ns;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) st3(g_src, i, rot_t(R, ld3(gP, i)));
-}
-
 // ---- O(1) adjoints, fp64 on one lane
 // adjoint of T = se3_exp(xi) (se3_exp_dev above, both branches) given gT (top 3 rows, row-major 3x4)
 __device__ void se3_exp_bwd(const float *xi, const double *gT, double *gxi) {
@@ -2222,7 +2149,6 @@ __device__ void se3_exp_bwd(const float *xi, const double *gT, double *gxi) {
 
 // sum of the 12-wide partial rows by a 256-thread block: 16 groups stride over the rows, then 12 threads
 // add the 16 group sums in order (nblocks <= BWD_MAXB)
-constexpr int BWD_ST = 256;
 __device__ __forceinline__ void reduce12(const float *__restrict__ partials, int nblocks, float *out_sm) {
     __shared__ float stage[12][17];
     const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -2274,17 +2200,16 @@ __device__ double solve_bwd(const float *H, float damp, const float *xi, const d
     return gd;
 }
 
-__global__ void bwd_init_k(BwdState *Sb, const float *__restrict__ grad_T) {
-    if (threadIdx.x < 16) Sb->gT[threadIdx.x] = grad_T[threadIdx.x];
-    if (threadIdx.x == 0) { Sb->gdamp = 0.0f; Sb->active = 0; }
-}
+// ---- the O(1) steps of the reverse pass, as device functions on a state in LDS (one lane; fp64 where the forward's
+// fp32 value would lose the gradient).  They run FOLDED into the prologue of the wide kernel that follows them, the way
+// the forward folds its step into the next association: every block recomputes the step from the previous launch's
+// outputs (state and partial sums: complete and visible at kernel start), block 0 alone publishes the new state; state
+// and partial sums alternate between two buffers from launch to launch.  Per gradLM iteration that is two launches
+// instead of four (S1 + look + S2 + lin were 7.3 + 11.4 + 5.7 + 11.6 us, profiles/r03n_fwd_bwd200_kernel_stats.csv).
+enum BwdFold { FOLD_G1 = 1, FOLD_G2 = 2, FOLD_LM = 3 };
 
 // S for one LM iteration (record = the STEP_LM record of that iteration)
-__global__ __launch_bounds__(BWD_ST) void bwd_small_lm_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
-                                                     int nblocks, int iter) {
-    __shared__ float sums[12];
-    reduce12(partials, nblocks, sums);
-    if (threadIdx.x != 0) return;
+__device__ void small_lm(BwdState *Sb, const float *__restrict__ rec, const float *sums, int iter) {
     const IcpState *S = rec_state(rec);
     if (rec[REC_ACCEPT] == 0.0f) { Sb->active = 0; return; }
     double gdT[12], gxi[6];
@@ -2308,11 +2233,7 @@ __global__ __launch_bounds__(BWD_ST) void bwd_small_lm_k(BwdState *Sb, const flo
 }
 
 // S1 for one gradLM iteration (record = its STEP_GRAD_B record; the next record's head = the state after)
-__global__ __launch_bounds__(BWD_ST) void bwd_small_g1_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
-                                                     int nblocks, GradParams gp, int prev_slot) {
-    __shared__ float sums[12];
-    reduce12(partials, nblocks, sums);
-    if (threadIdx.x != 0) return;
+__device__ void small_g1(BwdState *Sb, const float *__restrict__ rec, const float *sums, GradParams gp, int prev_slot) {
     const IcpState *S = rec_state(rec), *Sn = rec_state(rec + REC_WORDS);
     const float err = S->cur[42], new_err = rec[REC_LIN + 42];
     const float raw = new_err - err;
@@ -2345,11 +2266,7 @@ __global__ __launch_bounds__(BWD_ST) void bwd_small_g1_k(BwdState *Sb, const flo
 }
 
 // S2: look-ahead step dT1 = exp(xi) -> xi ; then the solve
-__global__ __launch_bounds__(BWD_ST) void bwd_small_g2_k(BwdState *Sb, const float *__restrict__ rec, const float *__restrict__ partials,
-                                                     int nblocks) {
-    __shared__ float sums[12];
-    reduce12(partials, nblocks, sums);
-    if (threadIdx.x != 0) return;
+__device__ void small_g2(BwdState *Sb, const float *__restrict__ rec, const float *sums) {
     const IcpState *S = rec_state(rec);
     double gdT1[12], gxi[6];
     for (int k = 0; k < 12; ++k) gdT1[k] = (double)sums[k];
@@ -2360,25 +2277,104 @@ __global__ __launch_bounds__(BWD_ST) void bwd_small_g2_k(BwdState *Sb, const flo
     Sb->G[42] = Sb->g_err; Sb->G[43] = 0.0f;
 }
 
-// adjoint of init_T: the T chain starts at init_T and src0 = init_T . user_src
-__global__ __launch_bounds__(BWD_ST) void bwd_small_end_k(const BwdState *Sb, const float *__restrict__ partials, int nblocks,
-                                                      float *__restrict__ g_init_T) {
+// prologue of the wide kernels: the folded small step on an LDS copy of the state; ends with a barrier
+__device__ __forceinline__ void bwd_fold(BwdState &sb, const BwdState *__restrict__ Sb_in, BwdState *__restrict__ Sb_out, int fold,
+                                         const float *__restrict__ rec, const float *__restrict__ partials_in, int nblocks,
+                                         GradParams gp, int arg) {
     __shared__ float sums[12];
-    reduce12(partials, nblocks, sums);
-    if (threadIdx.x < 16) g_init_T[threadIdx.x] = Sb->gT[threadIdx.x] + (threadIdx.x < 12 ? sums[threadIdx.x] : 0.0f);
+    constexpr int kWords = sizeof(BwdState) / 4;
+    static_assert(kWords <= BWD_T, "state copied by one pass of the block");
+    if (threadIdx.x < kWords) reinterpret_cast<int *>(&sb)[threadIdx.x] = reinterpret_cast<const int *>(Sb_in)[threadIdx.x];
+    reduce12(partials_in, nblocks, sums);  // ends with a barrier: sb and sums are visible
+    if (threadIdx.x == 0) {
+        if (fold == FOLD_G1) small_g1(&sb, rec, sums, gp, arg);
+        else if (fold == FOLD_G2) small_g2(&sb, rec, sums);
+        else small_lm(&sb, rec, sums, arg);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < kWords) reinterpret_cast<int *>(Sb_out)[threadIdx.x] = reinterpret_cast<const int *>(&sb)[threadIdx.x];
+}
+
+// B (gradLM), with S1 folded in: adjoint of new_err = e(look, NN(look)); gP_i <- R2^T gP_i + R1^T glook_i ; sums glook (x) s
+__global__ __launch_bounds__(BWD_T) void bwd_look_k(const BwdState *__restrict__ Sb_in, BwdState *__restrict__ Sb_out,
+                                                    const float *__restrict__ rec, const float *__restrict__ partials_in, int nblocks,
+                                                    GradParams gp, int prev_slot, LoopBufs B, const int32_t *__restrict__ d_ns,
+                                                    const float *__restrict__ tgt, const float *__restrict__ nrm, float thresh,
+                                                    float *__restrict__ gP, float *__restrict__ g_tgt, float *__restrict__ g_nrm,
+                                                    float *__restrict__ partials) {
+    __shared__ BwdState sb;
+    __shared__ float G[44];
+    bwd_fold(sb, Sb_in, Sb_out, FOLD_G1, rec, partials_in, nblocks, gp, prev_slot);
+    if (threadIdx.x < 44) G[threadIdx.x] = (threadIdx.x == 42) ? sb.g_new_err : 0.0f;
+    __syncthreads();
+    const float *R = sb.R2, *R1 = sb.R1;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    const float *src = B.P(sb.src_slot), *look = B.P(sb.look_slot);
+    const unsigned long long *nn = B.N(sb.look_slot);
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const Row r = make_row(look, tgt, nrm, nn, i, ns, thresh);
+        f3 gl{0.0f, 0.0f, 0.0f};
+        if (r.valid) gl = lin_point_bwd(G, r, ld3(look, i), (uint32_t)(nn[i] & 0xffffffffu), tgt, nrm, g_tgt, g_nrm);
+        acc_outer(acc, gl, ld3(src, i));
+        const f3 a = rot_t(R, ld3(gP, i)), b = rot_t(R1, gl);
+        st3(gP, i, f3{a.x + b.x, a.y + b.y, a.z + b.z});
+    }
+    block_store12(acc, partials);
+}
+
+// C, with S2 (gradLM) or S (LM) folded in: gP_i <- (rotate ? R2^T gP_i : gP_i) + adjoint of (H, g, e) at the iteration's
+// source cloud; sums of gP (x) predecessor cloud for the small step of the iteration that made this cloud
+__global__ __launch_bounds__(BWD_T) void bwd_lin_k(const BwdState *__restrict__ Sb_in, BwdState *__restrict__ Sb_out, int fold,
+                                                   const float *__restrict__ rec, const float *__restrict__ partials_in, int nblocks,
+                                                   int iter, int rotate, LoopBufs B, const float *__restrict__ user_src,
+                                                   const int32_t *__restrict__ d_ns, const float *__restrict__ tgt,
+                                                   const float *__restrict__ nrm, float thresh, float *__restrict__ gP,
+                                                   float *__restrict__ g_tgt, float *__restrict__ g_nrm,
+                                                   float *__restrict__ partials) {
+    __shared__ BwdState sb;
+    bwd_fold(sb, Sb_in, Sb_out, fold, rec, partials_in, nblocks, GradParams{}, iter);
+    if (!sb.active) {  // rejected LM iteration: gP stays as it is, the pending sums are handed on unchanged
+        if (threadIdx.x < 12) partials[blockIdx.x * 12 + threadIdx.x] = partials_in[blockIdx.x * 12 + threadIdx.x];
+        return;
+    }
+    const float *G = sb.G, *R = sb.R2;
+    const float *src = B.P(sb.src_slot);
+    const float *prev = sb.prev_slot >= 0 ? B.P(sb.prev_slot) : user_src;
+    const unsigned long long *nn = B.N(sb.nn_slot);
+    const int ns = *d_ns;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const Row r = make_row(src, tgt, nrm, nn, i, ns, thresh);
+        f3 g = ld3(gP, i);
+        if (rotate) g = rot_t(R, g);
+        if (r.valid) {
+            const f3 sb_ = lin_point_bwd(G, r, ld3(src, i), (uint32_t)(nn[i] & 0xffffffffu), tgt, nrm, g_tgt, g_nrm);
+            g.x += sb_.x; g.y += sb_.y; g.z += sb_.z;
+        }
+        st3(gP, i, g);
+        acc_outer(acc, g, ld3(prev, i));
+    }
+    block_store12(acc, partials);
 }
 
 struct BwdWs {
-    BwdState *S;
-    float *gP, *partials;
+    BwdState *S[2];       // double-buffered across launches (bwd_fold)
+    float *gP, *partials[2];
 };
 static inline size_t bwd_ws_layout(int max_ns, void *ws, BwdWs *out) {
-    const size_t oS = 0, oG = align_up(sizeof(BwdState), 256), oP = oG + align_up((size_t)max_ns * 12, 256);
+    const size_t sS = align_up(sizeof(BwdState), 256), sG = align_up((size_t)max_ns * 12, 256), sP = align_up((size_t)BWD_MAXB * 12 * 4, 256);
     if (ws && out) {
         char *p = (char *)ws;
-        out->S = (BwdState *)(p + oS); out->gP = (float *)(p + oG); out->partials = (float *)(p + oP);
+        out->S[0] = (BwdState *)p; out->S[1] = (BwdState *)(p + sS);
+        out->gP = (float *)(p + 2 * sS);
+        out->partials[0] = (float *)(p + 2 * sS + sG); out->partials[1] = (float *)(p + 2 * sS + sG + sP);
     }
-    return oP + align_up((size_t)BWD_MAXB * 12 * 4, 256);
+    return 2 * sS + sG + 2 * sP;
 }
 
 __global__ void zero_rows_k(float *__restrict__ a, float *__restrict__ b, const int32_t *__restrict__ d_n, int cap) {
@@ -2386,6 +2382,42 @@ __global__ void zero_rows_k(float *__restrict__ a, float *__restrict__ b, const 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (a) a[i] = 0.0f;
         if (b) b[i] = 0.0f;
+    }
+}
+
+// one launch for the reverse pass's preparations: gP and the first partial rows zeroed (nothing depends on the final
+// cloud), the target / normal adjoints zeroed over the rows that exist (max_nt may be a generous capacity), the state set
+__global__ void bwd_begin_k(BwdState *Sb, const float *__restrict__ grad_T, float *__restrict__ gP, int n_gp, float *__restrict__ partials,
+                            int n_part, float *__restrict__ g_tgt, float *__restrict__ g_nrm, const int32_t *__restrict__ d_nt, int cap) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = tid; i < n_gp; i += stride) gP[i] = 0.0f;
+    for (int i = tid; i < n_part; i += stride) partials[i] = 0.0f;
+    const int n = 3 * min(*d_nt, cap);
+    for (int i = tid; i < n; i += stride) {
+        if (g_tgt) g_tgt[i] = 0.0f;
+        if (g_nrm) g_nrm[i] = 0.0f;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 16) Sb->gT[threadIdx.x] = grad_T[threadIdx.x];
+        if (threadIdx.x == 0) { Sb->gdamp = 0.0f; Sb->active = 0; }
+    }
+}
+
+// last: through src0 = init_T . user_src; block 0 also adds the last partial sums up into the adjoint of init_T (the T
+// chain starts at init_T and src0 = init_T . user_src)
+__global__ __launch_bounds__(BWD_T) void bwd_finish_k(const float *__restrict__ init_T, const int32_t *__restrict__ d_ns,
+                                                      const float *__restrict__ gP, float *__restrict__ g_src,
+                                                      const BwdState *__restrict__ Sb, const float *__restrict__ partials, int nblocks,
+                                                      float *__restrict__ g_init_T) {
+    __shared__ float R[9];
+    __shared__ float sums[12];
+    if (threadIdx.x < 9) R[threadIdx.x] = init_T[4 * (threadIdx.x / 3) + threadIdx.x % 3];
+    __syncthreads();
+    const int ns = *d_ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) st3(g_src, i, rot_t(R, ld3(gP, i)));
+    if (blockIdx.x == 0) {  // (block-uniform)
+        reduce12(partials, nblocks, sums);
+        if (threadIdx.x < 16) g_init_T[threadIdx.x] = Sb->gT[threadIdx.x] + (threadIdx.x < 12 ? sums[threadIdx.x] : 0.0f);
     }
 }
 
@@ -2406,31 +2438,31 @@ static int icp_backward_run(bool grad, const float *src, const int32_t *d_ns, in
     BwdWs w;
     bwd_ws_layout(max_ns, ws, &w);
     const int nb = min(cdiv(max_ns, BWD_T), BWD_MAXB);
-    GS_HIP(hipMemsetAsync(w.gP, 0, (size_t)max_ns * 12, st), name);
-    GS_HIP(hipMemsetAsync(w.partials, 0, (size_t)nb * 12 * 4, st), name);  // nothing depends on the final cloud
-    if (g_tgt || g_nrm)  // only the rows that exist (max_nt may be a generous capacity)
-        hipLaunchKernelGGL(zero_rows_k, dim3(min(cdiv(3 * max_nt, 256), 1024)), dim3(256), 0, st, g_tgt, g_nrm, d_nt, max_nt);
-    hipLaunchKernelGGL(bwd_init_k, dim3(1), dim3(64), 0, st, w.S, grad_T);
+    int cur = 0;  // buffer the next launch READS its state / the previous sums from
+    hipLaunchKernelGGL(bwd_begin_k, dim3(min(cdiv(3 * max(max_nt, max_ns), 256), 1024)), dim3(256), 0, st, w.S[0], grad_T, w.gP, 3 * max_ns,
+                       w.partials[0], nb * 12, g_tgt, g_nrm, d_nt, max_nt);
     for (int k = numiters - 1; k >= 0; --k) {
         if (!grad) {
             const float *rec = tp.rec + (size_t)(1 + k) * REC_WORDS;
-            hipLaunchKernelGGL(bwd_small_lm_k, dim3(1), dim3(BWD_ST), 0, st, w.S, rec, w.partials, nb, k);
-            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 1, tp.B, src, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
-                               w.partials);
+            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, (const BwdState *)w.S[cur], w.S[1 - cur], (int)FOLD_LM, rec,
+                               (const float *)w.partials[cur], nb, k, 1, tp.B, src, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
+                               w.partials[1 - cur]);
+            cur = 1 - cur;
         } else {
             const float *rec = tp.rec + (size_t)(1 + 2 * k) * REC_WORDS;
             // slots of the gradLM loop are fixed: cloud k lives in slot 0 (k = 0) or 2k
-            hipLaunchKernelGGL(bwd_small_g1_k, dim3(1), dim3(BWD_ST), 0, st, w.S, rec, w.partials, nb, gp,
-                               k == 0 ? -1 : (k == 1 ? 0 : 2 * (k - 1)));
-            hipLaunchKernelGGL(bwd_look_k, dim3(nb), dim3(BWD_T), 0, st, w.S, tp.B, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
-                               w.partials);
-            hipLaunchKernelGGL(bwd_small_g2_k, dim3(1), dim3(BWD_ST), 0, st, w.S, rec, w.partials, nb);
-            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, w.S, 0, tp.B, src, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
-                               w.partials);
+            hipLaunchKernelGGL(bwd_look_k, dim3(nb), dim3(BWD_T), 0, st, (const BwdState *)w.S[cur], w.S[1 - cur], rec,
+                               (const float *)w.partials[cur], nb, gp, k == 0 ? -1 : (k == 1 ? 0 : 2 * (k - 1)), tp.B, d_ns, tgt, nrm, thresh,
+                               w.gP, g_tgt, g_nrm, w.partials[1 - cur]);
+            cur = 1 - cur;
+            hipLaunchKernelGGL(bwd_lin_k, dim3(nb), dim3(BWD_T), 0, st, (const BwdState *)w.S[cur], w.S[1 - cur], (int)FOLD_G2, rec,
+                               (const float *)w.partials[cur], nb, 0, 0, tp.B, src, d_ns, tgt, nrm, thresh, w.gP, g_tgt, g_nrm,
+                               w.partials[1 - cur]);
+            cur = 1 - cur;
         }
     }
-    hipLaunchKernelGGL(bwd_small_end_k, dim3(1), dim3(BWD_ST), 0, st, w.S, w.partials, nb, g_init_T);
-    hipLaunchKernelGGL(bwd_finish_k, dim3(nb), dim3(BWD_T), 0, st, init_T, d_ns, w.gP, g_src);
+    hipLaunchKernelGGL(bwd_finish_k, dim3(nb), dim3(BWD_T), 0, st, init_T, d_ns, (const float *)w.gP, g_src, (const BwdState *)w.S[cur],
+                       (const float *)w.partials[cur], nb, g_init_T);
     GS_LAUNCH_CHECK(name);
     return GS_OK;
 }

@@ -5,6 +5,7 @@
 set -o pipefail
 R=$PWD
 O=$R/gpurun_out/r03o; mkdir -p $O
+export GS_COMMIT=336d37d
 cd /tmp && export TMPDIR=/tmp
 echo "== pmc valu"; date
 GS_BENCH_SHORT=1 GS_BENCH_REPEATS=1 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_valu -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 > $O/pmc_valu.log 2>&1; echo "rc=$?"
