@@ -51,8 +51,12 @@ static inline int compact_blocks(int64_t n) { return n > 0 ? cdiv(n, kCB) : 1; }
 // workspace: block_counts[nb] + block_offsets[nb]
 static inline size_t compact_ws_bytes(int64_t n) { return align_up(2 * sizeof(int) * (size_t)compact_blocks(n), 256); }
 
+// `flags` (optional, one byte per thread = its kCI verdicts): the write pass then reads the verdicts instead of evaluating the
+// predicate again -- for predicates that cost more to evaluate than a byte costs to move (the projection: two IEEE
+// divisions per point; the write pass of a 1.7 M-point map took 18 us re-projecting, 12 B per point re-read).
 template <class Pred>
-__global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts) {
+__global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts,
+                                                       unsigned char *__restrict__ flags = nullptr) {
     __shared__ int sm[kCT / 64];
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     int c = 0;
@@ -64,19 +68,23 @@ __global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int
             pred.block_init(0);
             __syncthreads();
         }
+        int bits = 0;
 #pragma unroll
         for (int k = 0; k < kCI; ++k)
-            if (base + k < n && pred.test(it[k], base + k)) ++c;
+            if (base + k < n && pred.test(it[k], base + k)) { ++c; bits |= 1 << k; }
+        if (flags) flags[(int64_t)blockIdx.x * kCT + threadIdx.x] = (unsigned char)bits;
     } else {
         if constexpr (pred_has_block_init<Pred>::value) {
             pred.block_init(0);
             __syncthreads();
         }
+        int bits = 0;
 #pragma unroll
         for (int k = 0; k < kCI; ++k) {
             const int64_t i = base + k;
-            if (i < n && pred(i)) ++c;
+            if (i < n && pred(i)) { ++c; bits |= 1 << k; }
         }
+        if (flags) flags[(int64_t)blockIdx.x * kCT + threadIdx.x] = (unsigned char)bits;
     }
     c = wave_sum_i(c);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
@@ -148,8 +156,10 @@ __device__ __forceinline__ int self_scan_offset(const int *__restrict__ block_co
 template <class Pred, class Writer, bool SelfScan = false>
 __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Writer writer,
                                                        const int *__restrict__ block_offsets /* SelfScan: block COUNTS */,
-                                                       int *__restrict__ out_total = nullptr) {
+                                                       int *__restrict__ out_total = nullptr,
+                                                       const unsigned char *__restrict__ flags = nullptr) {
     __shared__ int sm[kCT / 64 + 1];
+    const int my_bits = flags ? flags[(int64_t)blockIdx.x * kCT + threadIdx.x] : 0;  // (requested before everything else)
     if constexpr (pred_has_block_init<Pred>::value) {
         pred.block_init(1);
         __syncthreads();
@@ -158,6 +168,22 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
     const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
     bool f[kCI];
     int c = 0;
+    if (flags) {  // the count pass's verdicts: no predicate, no fetch; the writer loads what it needs for the rows it writes
+#pragma unroll
+        for (int k = 0; k < kCI; ++k) { f[k] = (my_bits >> k) & 1; c += f[k] ? 1 : 0; }
+        int total;
+        int pos = block_base + block_excl_scan<kCT>(c, sm, &total);
+#pragma unroll
+        for (int k = 0; k < kCI; ++k) {
+            if (f[k]) {
+                writer(base + k, (int64_t)pos);
+                ++pos;
+            } else if constexpr (writer_has_skip<Writer>::value) {
+                if (base + k < n) writer.skip(base + k);
+            }
+        }
+        return;
+    }
     if constexpr (pred_has_fetch<Pred>::value) {
         typename Pred::Item it[kCI];
 #pragma unroll
@@ -203,23 +229,26 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
 // Enqueue the launches.  ws must hold compact_ws_bytes(n).
 // (A one-block, one-launch variant for small inputs was measured and rejected: 19 200 candidates on a single CU
 // take ~60 us of dependent gathers -- two launches spread over 19 blocks take ~9.)
+static inline size_t compact_flags_bytes(int64_t n) { return align_up((size_t)compact_blocks(n) * kCT, 256); }  // optional verdict bytes
+
 template <class Pred, class Writer>
 static inline int compact_launch(int64_t n, Pred pred, Writer writer, int *d_out_count, void *ws,
-                                 hipStream_t st, const char *name) {
+                                 hipStream_t st, const char *name, unsigned char *flags = nullptr /* compact_flags_bytes(n), or NULL */) {
     const int nb = compact_blocks(n);
     int *counts = (int *)ws;
     int *offsets = counts + nb;
-    hipLaunchKernelGGL((compact_count_k<Pred>), dim3(nb), dim3(kCT), 0, st, n, pred, counts);
+    hipLaunchKernelGGL((compact_count_k<Pred>), dim3(nb), dim3(kCT), 0, st, n, pred, counts, flags);
     GS_LAUNCH_CHECK(name);
     if (nb <= kSelfScanBlocks) {
-        hipLaunchKernelGGL((compact_write_k<Pred, Writer, true>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, counts, d_out_count);
+        hipLaunchKernelGGL((compact_write_k<Pred, Writer, true>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, counts, d_out_count,
+                           (const unsigned char *)flags);
         GS_LAUNCH_CHECK(name);
         return GS_OK;
     }
     hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, st, counts, nb, offsets, d_out_count);
     GS_LAUNCH_CHECK(name);
     hipLaunchKernelGGL((compact_write_k<Pred, Writer, false>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, offsets,
-                       (int *)nullptr);
+                       (int *)nullptr, (const unsigned char *)flags);
     GS_LAUNCH_CHECK(name);
     return GS_OK;
 }

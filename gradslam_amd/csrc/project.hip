@@ -356,7 +356,7 @@ namespace gs {
 // gs_project_active (ds-grid) + gs_build_icp_target for one sequence in 4 launches instead of 6 (see ActivePredH)
 size_t project_target1_ws_bytes(int H, int W, int ds, int Nmax) {
     const size_t npix = (size_t)cdiv(H, ds) * cdiv(W, ds);
-    return compact_ws_bytes(Nmax) + 2 * align_up(npix * 4, 256);
+    return compact_ws_bytes(Nmax) + 2 * align_up(npix * 4, 256) + compact_flags_bytes(Nmax);
 }
 int project_target1(const float *points, const int32_t *counts, int Nmax, const float *poses, const float *intrinsics, int H,
                     int W, int ds, const float *map_normals, int cap, int64_t *rows, int32_t *nrows, float *tgt, float *tnrm,
@@ -371,10 +371,11 @@ int project_target1(const float *points, const int32_t *counts, int Nmax, const 
     char *p = (char *)ws;
     void *cws = p; p += compact_ws_bytes(Nmax);
     int *cnt = (int *)p, *fill = (int *)(p + align_up((size_t)npix * 4, 256));
+    unsigned char *flags = (unsigned char *)(p + 2 * align_up((size_t)npix * 4, 256));  // the count pass's verdicts for the write pass
     const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
     ActivePredH pred{points, counts, poses, intrinsics, Nmax, H, W, ds, umax, vmax, cnt, fill, npix};
     ActiveWriterH wr{points, rows, H, W, ds, Wd, umax, vmax, cnt};
-    const int rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name);
+    const int rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name, flags);
     if (rc) return rc;
     hipLaunchKernelGGL(pix_scan_k, dim3(1), dim3(1024), 0, st, cnt, npix, pix_start);
     hipLaunchKernelGGL(tgt_scatter_gather1_k, dim3(min(cdiv(Nmax, 256), 1024)), dim3(256), 0, st, rows, nrows, points, map_normals, cap,

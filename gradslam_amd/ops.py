@@ -513,18 +513,24 @@ def icp_loop_autograd(src, tgt, nrm, init_T, numiters, damp, dist_thresh, grad_p
 
 
 def slam_localize_raw(depth, K, prev_poses, map_points, map_normals, map_counts_i32, ds, numiters, damp, dist_thresh,
-                      grad_params=None):
+                      grad_params=None, out=None, want_maps=True):
     """One fused, sync-free ICPSLAM._localize (reference slam/icpslam.py:238-247).
     depth (B,1,H,W,1), K (B,1,4,4), prev_poses (B,1,4,4), map padded (B,Nmax,3) x2 + counts (B,) int32.
-    Returns (poses (B,1,4,4), V, N): the local maps are handed back so the caller can cache them."""
+    Returns (poses (B,1,4,4), V, N): the local maps are handed back so the caller can cache them (want_maps=False: not
+    computed, None returned).  `out`: a contiguous float32 (B,1,4,4) tensor the poses are written to (a sequence driver's
+    slice of its pose array: no copy launch)."""
     require_hip(depth, K, prev_poses, map_points, map_normals, map_counts_i32, op="slam_localize")
     depth, K, prev = _f32c(depth.detach()), _f32c(K.detach()), _f32c(prev_poses.detach())
     mp, mn = _f32c(map_points.detach()), _f32c(map_normals.detach())
     B, _, H, W = depth.shape[:4]
     Nmax = mp.shape[1]
     dev = depth.device
-    V, N, gV = (torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(3))
-    out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+    mk = lambda: torch.empty((B, 1, H, W, 3), dtype=torch.float32, device=dev)
+    V, N, gV = (mk() if want_maps else None), (mk() if want_maps else None), mk()
+    if out is None:
+        out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+    elif not (out.is_contiguous() and out.dtype == torch.float32 and out.numel() == 16 * B and out.device == dev):
+        raise ValueError("slam_localize: `out` must be a contiguous float32 (B,1,4,4) tensor on the inputs' device")
     ws = workspace(ws_bytes("gs_slam_localize_ws_bytes", B, H, W, int(ds), Nmax), dev, "localize")
     lmax, Bp, B2, nu = grad_params if grad_params is not None else (2.0, 1.0, 1.0, 200.0)
     call("gs_slam_localize", ptr(depth), ptr(K), ptr(prev), B, H, W, int(ds), ptr(mp), ptr(mn), ptr(map_counts_i32), Nmax,
