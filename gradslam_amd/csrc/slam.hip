@@ -97,7 +97,6 @@ struct LocWs {
     float *scan;       // (B, capT, 3) target points in pixel order
     int32_t *scan_orig;// (B, capT)
     int32_t *pix_start;// (B, capS + 1) first scan slot of every ds-grid pixel
-    int32_t *tgt_pix;  // (B, capT) ds-grid pixel of every target (reference order)
     int32_t *ns;       // (B)
     int64_t *rows;     // (B*Nmax, 4)
     int32_t *nrows;    // (1)
@@ -125,7 +124,6 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
     const size_t o_src = take((size_t)B * capS * 12), o_ns = take((size_t)B * 4);
     const size_t o_spix = take((size_t)B * capS * 4), o_scan = take((size_t)B * capT * 12);
     const size_t o_sorig = take((size_t)B * capT * 4), o_pseed = take((size_t)B * (capS + 1) * 4);
-    const size_t o_tpix = take((size_t)B * capT * 4);
     // NB every size below depends on (B, H, W, ds, capT) only -- never on Nmax itself -- so that pointers baked
     // into a captured graph stay valid while the map grows inside one capacity bucket
     const size_t o_rows = take((size_t)B * capT * 32), o_nrows = take(4);
@@ -143,7 +141,6 @@ static size_t loc_layout(int B, int H, int W, int ds, int Nmax, void *ws, LocWs 
         out->src = (float *)(p + o_src); out->ns = (int32_t *)(p + o_ns);
         out->src_pix = (int32_t *)(p + o_spix); out->scan = (float *)(p + o_scan);
         out->scan_orig = (int32_t *)(p + o_sorig); out->pix_start = (int32_t *)(p + o_pseed);
-        out->tgt_pix = (int32_t *)(p + o_tpix);
         out->rows = (int64_t *)(p + o_rows); out->nrows = (int32_t *)(p + o_nrows);
         out->tgt = (float *)(p + o_tgt); out->tnrm = (float *)(p + o_tnrm); out->nt = (int32_t *)(p + o_nt);
         out->T = (float *)(p + o_T); out->eye = (float *)(p + o_eye); out->cam = (float *)(p + o_cam);
@@ -362,12 +359,12 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     // slot of every ds-grid pixel (search hints only); one sequence takes the 4-launch fused form
     if (B == 1) {
         if ((rc = project_target1(map_points, map_counts, Nmax, prev_poses, intrinsics, H, W, ds, map_normals, capT, w.rows, w.nrows,
-                                  w.tgt, w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.tgt_pix, w.sub, w.sub_bytes, st))) return rc;
+                                  w.tgt, w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, nullptr, w.sub, w.sub_bytes, st))) return rc;
     } else {
         if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
                                     w.sub_bytes, stream))) return rc;
         if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
-                                      w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, w.tgt_pix, w.sub, w.sub_bytes, stream))) return rc;
+                                      w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, nullptr, w.sub, w.sub_bytes, stream))) return rc;
     }
     // fold_compose: the loop's last launch also writes out_poses = T . prev_poses.  Only for eager launches: a
     // captured graph must not bake the caller's prev_poses / out_poses addresses in (they change every call).
@@ -376,7 +373,7 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
             const float *src = w.src + (size_t)b * capS * 3;
             const float *tgt = w.tgt + (size_t)b * capT * 3, *nrm = w.tnrm + (size_t)b * capT * 3;
             const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, w.src_pix + (size_t)b * capS,
-                                     w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds),
+                                     w.pix_start + (size_t)b * (capS + 1), nullptr, cdiv(W, ds), cdiv(H, ds),
                                      w.cam + 32 * b, w.cam + 32 * b + 16, ds};
             // the loop's last launch also writes out_poses[b] = T . prev_poses[b]
             const int r = icp_localize_run(use_grad_lm, src, w.ns + b, capS, tgt, nrm, w.nt + b, capT, numiters, damp, dist_thresh,
@@ -644,17 +641,17 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
                                   w.sub, w.sub_bytes, stream))) return rc;
     if (B == 1) {
         if ((rc = project_target1(map_points, map_counts, Nmax, prev_poses, intrinsics, H, W, ds, map_normals, capT, w.rows, w.nrows,
-                                  w.tgt, w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.tgt_pix, w.sub, w.sub_bytes,
+                                  w.tgt, w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, nullptr, w.sub, w.sub_bytes,
                                   (hipStream_t)stream))) return rc;
     } else {
         if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
                                     w.sub_bytes, stream))) return rc;
         if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
-                                      w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, w.tgt_pix, w.sub, w.sub_bytes, stream))) return rc;
+                                      w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, nullptr, w.sub, w.sub_bytes, stream))) return rc;
     }
     for (int b = 0; b < B; ++b) {
         const gs_icp_hints hints{w.scan + (size_t)b * capT * 3, w.scan_orig + (size_t)b * capT, tp.src_pix + (size_t)b * capS,
-                                 w.pix_start + (size_t)b * (capS + 1), w.tgt_pix + (size_t)b * capT, cdiv(W, ds), cdiv(H, ds),
+                                 w.pix_start + (size_t)b * (capS + 1), nullptr, cdiv(W, ds), cdiv(H, ds),
                                  prev_poses + 16 * b, intrinsics + 16 * b, ds};
         if ((rc = icp_localize_run(use_grad_lm, tp.src + (size_t)b * capS * 3, tp.ns + b, capS, w.tgt + (size_t)b * capT * 3,
                                    w.tnrm + (size_t)b * capT * 3, tp.nt + b, capT, numiters, damp, dist_thresh, lambda_max, Bp, B2, nu,
