@@ -1335,25 +1335,30 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     // ---- the O(1) step is wave 0's; GRID: the other fifteen waves meanwhile work out the window of every lane and the
     // row bands of the tile, stage the bands' targets into LDS and fetch the seed for either outcome of the step.
     // Nothing of that depends on the step, so it costs the association no time.
-    // GRID, staging waves: the FRONT of the staging -- window centre, the tile's displacement and row bands, and the REQUESTS
-    // for the bands' first slots, wave 1's window rows and its seeds -- runs from reduce_partials' hook: after the partial rows
-    // of the folded step have been requested, before they are consumed.  The early loads above were issued before the rows,
-    // so waiting for them costs the rows nothing; what the front requests then travels while the rows are summed (two
-    // barriers, ~1.5 us), instead of starting after them (phase stamps r03l: bands known 5.1 us after kernel entry, block
-    // barrier at 7.8, the step itself done at 4.5).
-    const int g_Wd = C->hints.grid_w, g_nc = C->hints.grid_w * C->hints.grid_h;
-    int g_c = 0, g_rel = 2;
-    bool g_in = false;
-    int lo_raw[WBANDS], hi_raw[WBANDS], row_lo[WROWS], row_hi[WROWS];
-    bool want[WBANDS];
-    float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-#pragma unroll
-    for (int kk = 0; kk < WBANDS; ++kk) { lo_raw[kk] = 0; hi_raw[kk] = 0; want[kk] = false; }
-#pragma unroll
-    for (int r = 0; r < WROWS; ++r) { row_lo[r] = 0; row_hi[r] = 0; }
-    auto staging_front = [&]() {
-        if (!(GRID && grid && tile_live && wave != 0)) return;
-        const int Wd = g_Wd, nc = g_nc;
+    if (step_mode >= 0) {
+        // (rows of surplus blocks -- see above -- are zeros behind every thread's last live row: not read)
+        reduce_partials(partials_in, min(nblocks_in, (ns + C->tile_points - 1) / C->tile_points), acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
+        // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
+        if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
+    }
+    if (wave == 0) {
+        const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
+        if (step_mode >= 0)
+            step_wave0(&st_sm, acc_sm, step_mode, C->gp, pub ? C->trace : nullptr, pub ? C->out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm, true);
+    } else if (!grid && tile_live && !first && wave == 1) {
+        // chunk-box search: the seed (the previous neighbour's target point) for either outcome of the step, fetched
+        // while wave 0 computes it -- two dependent loads less on the association's critical path
+        if (ok) {
+            const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
+            const unsigned long long ka = B.N(ba)[i], kb = B.N(bb)[i];
+            // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
+            const int sa = (int)min((uint32_t)(ka & 0xffffffffu), (uint32_t)(nt - 1)), sb = (int)min((uint32_t)(kb & 0xffffffffu), (uint32_t)(nt - 1));
+            const f3 qa = ld3(C->tgt, sa), qb = ld3(C->tgt, sb);
+            *reinterpret_cast<float4 *>(sh.seed[0][lane]) = make_float4(qa.x, qa.y, qa.z, __int_as_float(sa));
+            *reinterpret_cast<float4 *>(sh.seed[1][lane]) = make_float4(qb.x, qb.y, qb.z, __int_as_float(sb));
+        }
+    } else if (grid && tile_live) {
+        const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
         const int h = ok ? min(max(e_h, 0), nc - 1) : 0;
         // Window centre: the grid pixel the point projects to.  The point itself is only known once the step (wave 0,
         // concurrently) has produced dT -- but it is within millimetres of the cloud the PREVIOUS launch wrote, whatever
@@ -1363,7 +1368,11 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         // actual position against it.
         int c = h;
         if (ok && C->cam_ok) c = first ? cam_cell(C->cam, xform(S_in->dT, e_pp)) : min(max(e_c, 0), nc - 1);
-        // wave 1: the first / one-past-last slots of the lane's three window rows, requested as soon as the centre is known
+        // wave 1: the first / one-past-last slots of the lane's three window rows -- requested as soon as the centre is known,
+        // ahead of the tile's reductions and band loads (they used to leave last and the block's barrier waited for them)
+        int row_lo[WROWS], row_hi[WROWS];
+#pragma unroll
+        for (int r = 0; r < WROWS; ++r) { row_lo[r] = 0; row_hi[r] = 0; }
         if (wave == 1) {
 #pragma unroll
             for (int r = 0; r < WROWS; ++r) {
@@ -1372,6 +1381,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 row_hi[r] = C->hints.pix_start[min(max(g + 1, 0), nc - 1) + 1];
             }
         }
+        float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
             int sj[2];
             if (first) {
@@ -1422,57 +1432,29 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         // two rows), R = 1 (radius 2 = five rows, six bands was measured: ~1 us per launch more on a dense target, nothing
         // gained on a sparse one).  All first-slot loads are issued before any is used: taken one band after the other
         // they were four dependent trips through the scalar cache (2.4 us, r03h).
-#pragma unroll
-        for (int kk = 0; kk < WBANDS; ++kk) {
-            const int a = bmin + (kk - 1) * Wd - 1, b = bmax + (kk - 1) * Wd + 1;
-            want[kk] = kk <= 2 + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1;
-            lo_raw[kk] = C->hints.pix_start[min(max(a, 0), nc - 1)];
-            hi_raw[kk] = C->hints.pix_start[min(max(b, 0), nc - 1) + 1];
-        }
-        g_c = c; g_rel = rel; g_in = in;
-    };
-    if (step_mode >= 0) {
-        // (rows of surplus blocks -- see above -- are zeros behind every thread's last live row: not read)
-        reduce_partials(partials_in, min(nblocks_in, (ns + C->tile_points - 1) / C->tile_points), acc_sm, staging_front);  // ends with a barrier: st_sm and acc_sm are visible
-        // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
-        if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
-    } else {
-        staging_front();
-    }
-    if (wave == 0) {
-        const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
-        if (step_mode >= 0)
-            step_wave0(&st_sm, acc_sm, step_mode, C->gp, pub ? C->trace : nullptr, pub ? C->out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm, true);
-    } else if (!grid && tile_live && !first && wave == 1) {
-        // chunk-box search: the seed (the previous neighbour's target point) for either outcome of the step, fetched
-        // while wave 0 computes it -- two dependent loads less on the association's critical path
-        if (ok) {
-            const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
-            const unsigned long long ka = B.N(ba)[i], kb = B.N(bb)[i];
-            // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
-            const int sa = (int)min((uint32_t)(ka & 0xffffffffu), (uint32_t)(nt - 1)), sb = (int)min((uint32_t)(kb & 0xffffffffu), (uint32_t)(nt - 1));
-            const f3 qa = ld3(C->tgt, sa), qb = ld3(C->tgt, sb);
-            *reinterpret_cast<float4 *>(sh.seed[0][lane]) = make_float4(qa.x, qa.y, qa.z, __int_as_float(sa));
-            *reinterpret_cast<float4 *>(sh.seed[1][lane]) = make_float4(qb.x, qb.y, qb.z, __int_as_float(sb));
-        }
-    } else if (grid && tile_live) {
-        // the BACK of the staging: the bands from what the front requested, the targets into registers, then LDS
-        const int Wd = g_Wd, nc = g_nc;
-        const int c = g_c;
-        int rel = g_rel;
-        const bool in = g_in;
         constexpr int R = 1;
         int bbase[WBANDS], boff[WBANDS], bcnt[WBANDS], used = 0;
+        {
+            int lo_raw[WBANDS], hi_raw[WBANDS];
+            bool want[WBANDS];
 #pragma unroll
-        for (int kk = 0; kk < WBANDS; ++kk) {
-            bbase[kk] = 0; bcnt[kk] = 0; boff[kk] = used;
-            const int lo = min(max(lo_raw[kk], 0), nt) & ~(CHUNK - 1);
-            const int hi = min((min(max(hi_raw[kk], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt);
-            if (want[kk] && hi > lo) {
-                bbase[kk] = lo; bcnt[kk] = hi - lo;
-                // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
-                // window stays complete and with it the proof): pool offset -1
-                if (used + (hi - lo) <= POOL) used += hi - lo; else boff[kk] = -1;
+            for (int kk = 0; kk < WBANDS; ++kk) {
+                const int a = bmin + (kk - R) * Wd - R, b = bmax + (kk - R) * Wd + R;
+                want[kk] = kk <= 2 * R + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1;
+                lo_raw[kk] = C->hints.pix_start[min(max(a, 0), nc - 1)];
+                hi_raw[kk] = C->hints.pix_start[min(max(b, 0), nc - 1) + 1];
+            }
+#pragma unroll
+            for (int kk = 0; kk < WBANDS; ++kk) {
+                bbase[kk] = 0; bcnt[kk] = 0; boff[kk] = used;
+                const int lo = min(max(lo_raw[kk], 0), nt) & ~(CHUNK - 1);
+                const int hi = min((min(max(hi_raw[kk], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt);
+                if (want[kk] && hi > lo) {
+                    bbase[kk] = lo; bcnt[kk] = hi - lo;
+                    // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
+                    // window stays complete and with it the proof): pool offset -1
+                    if (used + (hi - lo) <= POOL) used += hi - lo; else boff[kk] = -1;
+                }
             }
         }
         GS_STAMP(14);

@@ -623,7 +623,7 @@ def aggregate_update_raw(depth, rgb, K, poses, map_points, map_normals, map_colo
 
 
 class _PointFusionSeqFn(torch.autograd.Function):
-    """PointFusion over a whole sequence as ONE autograd node (one sequence: B = 1).
+    """PointFusion over a whole batch of sequences as ONE autograd node.
 
     forward  = the arena-backed frame loop with the taped forms of its two calls per frame
                (gs_slam_localize_taped, gs_pointfusion_update_taped): no host synchronisation until the map is
@@ -686,14 +686,15 @@ class _PointFusionSeqFn(torch.autograd.Function):
         ctx.has_poses = poses is not None
         ctx.save_for_backward(rgb, depth, K, recovered)
         ctx.stats = stats
-        cut = lambda x: x[:, : n[0]].clone()
+        cut = lambda x: x[:, : max(n)].clone()  # zero-padded to the largest map (rows beyond a sequence's count are zero)
+        ctx.mark_non_differentiable(stats)
         return cut(arena.points), cut(arena.normals), cut(arena.colors), cut(arena.ccounts), recovered.clone(), stats
 
     @staticmethod
     def backward(ctx, g_p, g_n, g_c, g_f, g_poses, _g_stats):
         rgb, depth, K, recovered = ctx.saved_tensors
         odom, ds, numiters, thresh, grad_lm, lmax, Bp, B2, nu, sigma = ctx.cfg
-        arena, frames, n_final = ctx.arena, ctx.frames, ctx.n_final[0]
+        arena, frames, n_final = ctx.arena, ctx.frames, ctx.n_final
         B, L, H, W = depth.shape[:4]
         dev = depth.device
         cap = arena.cap
@@ -704,7 +705,8 @@ class _PointFusionSeqFn(torch.autograd.Function):
         def running(g, c):
             G = torch.zeros((B, cap, c), dtype=torch.float32, device=dev)
             if g is not None:
-                G[:, :n_final] = g
+                for b in range(B):  # (rows beyond a sequence's count are padding of the output, not map points)
+                    G[b, :n_final[b]] = g[b, :n_final[b]]
             return G
 
         Gp, Gn, Gc, Gf = running(g_p, 3), running(g_n, 3), running(g_c, 3), running(g_f, 1)
@@ -717,28 +719,44 @@ class _PointFusionSeqFn(torch.autograd.Function):
         g_prev = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
         # One sequence (B = 1): the per-frame slices of the adjoints are contiguous, so every kernel writes or ADDS straight
         # into them -- no per-frame temporaries, zero fills or `+=` launches (a dozen small torch kernels per frame, and
-        # their host cost, in the first version of this loop).
+        # their host cost, in the first version of this loop).  A batch takes contiguous per-frame buffers and copies.
+        one = B == 1
+        if not one:
+            t_rgb, t_depth, t_pose, t_pose2 = mk(3), torch.empty((B, 1, H, W, 1), dtype=torch.float32, device=dev), \
+                torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev), torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
         for s in reversed(range(L)):
-            d_s, c_s = depth[:, s], rgb[:, s]
-            pose_s = recovered[:, s:s + 1]
+            d_s, c_s = depth[:, s].contiguous(), rgb[:, s].contiguous()
+            pose_s = recovered[:, s:s + 1].contiguous()
             ftape, bound = frames[s]["fuse"]
             ws = workspace(ws_bytes("gs_pointfusion_update_backward_ws_bytes", B, H, W), dev, "fusion_bwd")
             call("gs_pointfusion_update_backward", ptr(d_s), ptr(c_s), ptr(K), ptr(pose_s), B, H, W, ptr(mp), ptr(mn), ptr(mc), ptr(mf),
                  ptr(counts), bound, sigma, ptr(ftape), ftape.numel(), ptr(Gp), ptr(Gn), ptr(Gc), ptr(Gf), ptr(g_V), ptr(g_gV),
-                 ptr(g_gN), ptr(g_rgb[:, s]), ptr(ws), ws.numel(), stream())
+                 ptr(g_gN), ptr(g_rgb[:, s] if one else t_rgb), ptr(ws), ws.numel(), stream())
+            if one:
+                gd_s, gpose_s = g_depth[:, s], gpose[:, s]
+            else:
+                g_rgb[:, s] = t_rgb
+                gd_s, gpose_s = t_depth.zero_(), t_pose.zero_()
             vertex_normal_maps_backward_into(d_s.unsqueeze(1), K, pose_s, g_V.unsqueeze(1), None, g_gV.unsqueeze(1), g_gN.unsqueeze(1),
-                                             g_depth[:, s], g_K, gpose[:, s])
+                                             gd_s, g_K, gpose_s)
+            if not one:
+                gpose[:, s] += t_pose[:, 0]
             if "loc" in frames[s]:
                 tape, nmax = frames[s]["loc"]
-                prev = recovered[:, s - 1:s]
+                prev = recovered[:, s - 1:s].contiguous()
                 ws = workspace(ws_bytes("gs_slam_localize_backward_ws_bytes", B, H, W, ds, nmax), dev, "localize_bwd")
                 call("gs_slam_localize_backward", ptr(prev), B, H, W, ds, ptr(mp), ptr(mn), nmax, grad_lm, numiters, thresh, lmax, Bp, B2,
-                     nu, ptr(tape), tape.numel(), ptr(gpose[:, s:s + 1]), ptr(g_live), ptr(Gp), ptr(Gn), ptr(g_prev), 1,
+                     nu, ptr(tape), tape.numel(), ptr(gpose[:, s:s + 1].contiguous()), ptr(g_live), ptr(Gp), ptr(Gn), ptr(g_prev), 1,
                      ptr(ws), ws.numel(), stream())
-                vertex_normal_maps_backward_into(d_s.unsqueeze(1), K, prev, None, None, g_live, None, g_depth[:, s], g_K, gpose[:, s - 1])
+                gprev_s = gpose[:, s - 1] if one else t_pose2.zero_()
+                vertex_normal_maps_backward_into(d_s.unsqueeze(1), K, prev, None, None, g_live, None, gd_s, g_K, gprev_s)
+                if not one:
+                    gpose[:, s - 1] += t_pose2[:, 0]
                 gpose[:, s - 1] += g_prev.view(B, 4, 4)
             elif g_poses_in is not None:
                 g_poses_in[:, s] += gpose[:, s]
+            if not one:
+                g_depth[:, s] += t_depth[:, 0]
         return g_rgb, g_depth, g_K, g_poses_in, None
 
 

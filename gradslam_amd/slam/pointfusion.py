@@ -54,7 +54,7 @@ class PointFusion(ICPSLAM):
                                    stats_row)
 
     def _can_fuse_sequence(self, frames) -> bool:
-        """forward() with gradients as one node: one channels-last float32 sequence on the device, the mapping step not
+        """forward() with gradients as one node: channels-last float32 sequences on the device, the mapping step not
         overridden by a subclass."""
         if not getattr(type(self)._map, "_gs_arena_form", False) or frames.channels_first or self.device.type != "cuda":
             return False
@@ -65,13 +65,13 @@ class PointFusion(ICPSLAM):
             return False
         if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)):
             return False  # nothing to differentiate: the streamed / step-by-step drivers
-        if not (frames.shape[0] == 1 and frames.shape[2] >= 2 and frames.shape[3] >= 2):
+        if not (frames.shape[0] <= 60 and frames.shape[2] >= 2 and frames.shape[3] >= 2):
             return False
         # Memory law of the sequence node: it keeps, until backward, one fusion tape (44 B per pixel) and one localisation
         # tape (the ICP loop's clouds and neighbour arrays, ~20 B per ds-grid point and association, + 4 B per target slot)
         # per frame, and the arena -- ~7.7 GB for 200 frames of 640x480.  A sequence whose tapes would not fit takes the
         # per-frame nodes instead (slower, but every frame's intermediates are freed as autograd walks back).
-        need = self.sequence_tape_bytes(frames.shape[1], frames.shape[2], frames.shape[3])
+        need = frames.shape[0] * self.sequence_tape_bytes(frames.shape[1], frames.shape[2], frames.shape[3])
         free = torch.cuda.mem_get_info(frames.device)[0]
         if need > 0.8 * free:
             warnings.warn("PointFusion: the one-node differentiable sequence would keep ~{:.1f} GB of tapes ({:.1f} GB free): "
@@ -107,7 +107,9 @@ class PointFusion(ICPSLAM):
             if row[2]:
                 raise RuntimeError("map arena overflow at frame {} (internal capacity bound violated)".format(s))
             self._stream_warnings(s, row)
-        return Pointclouds(points=[pts[0]], normals=[nrm[0]], colors=[col[0]], features=[cc[0]]), poses
+        n = [int(x) for x in stats[:, 4:4 + pts.shape[0]].sum(0).tolist()]  # rows every sequence's map holds (appended, summed)
+        pick = lambda x: [x[b, : n[b]] for b in range(x.shape[0])]
+        return Pointclouds(points=pick(pts), normals=pick(nrm), colors=pick(col), features=pick(cc)), poses
 
     def _stream_warnings(self, s, row):
         if s == 0:

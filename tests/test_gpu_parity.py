@@ -1578,3 +1578,36 @@ def test_dense_regime_step_vs_oracle(gs, odom, k):
         bad = ((a - r).abs().amax(1) > 1e-4 * r.abs().max()).float().mean().item()
         print("   ", nm, "merged rows off by > 1e-4 of the maximum:", bad)
         assert bad < 1e-3, (nm, bad)
+
+
+@pytest.mark.parametrize("odom", ["gt", "gradicp"])
+def test_sequence_node_batch_equals_single_runs(gs, odom):
+    """The sequence-level autograd node on a BATCH: three sequences of different lengths of map in one
+    call against three single-sequence calls -- poses and maps bit for bit (sequences never interact), all four input
+    gradients to 1e-5 of their maximum (the scattered target adjoints are float atomics: ~1e-7)."""
+    from gradslam_amd.synthetic import make_sequence
+
+    B, L = 3, 4
+    c0, d0, K0, P0 = make_sequence(B, L, 96, 128, seed=81)
+    d0[1, :, :, 40:70] = 0.0  # a different hole pattern per sequence: ragged maps
+    d0[2, :, 30:50] = 0.0
+
+    def run(sl):
+        leaves = [x[sl].to(DEV).clone().requires_grad_(True) for x in (c0, d0, K0, P0)]
+        slam = gs.slam.PointFusion(odom=odom, dsratio=2, numiters=5, device=DEV)
+        pcs, poses = slam(gs.RGBDImages(*leaves))
+        loss = (poses * torch.linspace(0.5, 1.5, poses[0].numel(), device=DEV).view_as(poses[0])).sum() + pcs.points_padded.sum() + \
+            (pcs.normals_padded * 0.3).sum() + pcs.colors_padded.mean() * pcs.colors_padded.numel() * 1e-6 + (pcs.features_padded ** 2).sum() * 1e-3
+        loss.backward()
+        return pcs, poses.detach(), [x.grad if x.grad is not None else torch.zeros_like(x) for x in leaves]
+
+    pcs, poses, grads = run(slice(0, B))
+    assert len(set(pcs.num_points_per_pointcloud.tolist())) == B  # really ragged
+    for b in range(B):
+        spcs, sposes, sgrads = run(slice(b, b + 1))
+        assert torch.equal(poses[b], sposes[0]), b
+        for attr in ("points_list", "normals_list", "colors_list", "features_list"):
+            assert torch.equal(getattr(pcs, attr)[b].detach(), getattr(spcs, attr)[0].detach()), (b, attr)
+        for name, g, sg in zip(("colors", "depths", "intrinsics", "poses"), grads, sgrads):
+            e = rel_err(g[b].cpu(), sg[0].cpu())
+            assert e < 1e-5, (odom, b, name, e)
