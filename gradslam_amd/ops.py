@@ -724,10 +724,24 @@ class _PointFusionSeqFn(torch.autograd.Function):
         if not one:
             t_rgb, t_depth, t_pose, t_pose2 = mk(3), torch.empty((B, 1, H, W, 1), dtype=torch.float32, device=dev), \
                 torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev), torch.empty((B, 1, 4, 4), dtype=torch.float32, device=dev)
+        stride = cap
+
+        def restride(n):
+            # A batch's arrays are (B, stride, C) and the kernels take ONE number for row bound and row stride.  The arena
+            # may have grown during the forward pass; the tapes of earlier frames were laid out with the stride of their
+            # time.  Walking back, the map only shrinks: repack the working arrays to the older, smaller stride once per
+            # growth step (rows beyond it did not exist yet; their adjoints have been consumed by their own frames).
+            nonlocal mp, mn, mc, mf, Gp, Gn, Gc, Gf, stride
+            if one or n == stride:
+                return
+            mp, mn, mc, mf, Gp, Gn, Gc, Gf = (x[:, :n].contiguous() for x in (mp, mn, mc, mf, Gp, Gn, Gc, Gf))
+            stride = n
+
         for s in reversed(range(L)):
             d_s, c_s = depth[:, s].contiguous(), rgb[:, s].contiguous()
             pose_s = recovered[:, s:s + 1].contiguous()
             ftape, bound = frames[s]["fuse"]
+            restride(bound)
             ws = workspace(ws_bytes("gs_pointfusion_update_backward_ws_bytes", B, H, W), dev, "fusion_bwd")
             call("gs_pointfusion_update_backward", ptr(d_s), ptr(c_s), ptr(K), ptr(pose_s), B, H, W, ptr(mp), ptr(mn), ptr(mc), ptr(mf),
                  ptr(counts), bound, sigma, ptr(ftape), ftape.numel(), ptr(Gp), ptr(Gn), ptr(Gc), ptr(Gf), ptr(g_V), ptr(g_gV),
@@ -743,6 +757,7 @@ class _PointFusionSeqFn(torch.autograd.Function):
                 gpose[:, s] += t_pose[:, 0]
             if "loc" in frames[s]:
                 tape, nmax = frames[s]["loc"]
+                restride(nmax)
                 prev = recovered[:, s - 1:s].contiguous()
                 ws = workspace(ws_bytes("gs_slam_localize_backward_ws_bytes", B, H, W, ds, nmax), dev, "localize_bwd")
                 call("gs_slam_localize_backward", ptr(prev), B, H, W, ds, ptr(mp), ptr(mn), nmax, grad_lm, numiters, thresh, lmax, Bp, B2,

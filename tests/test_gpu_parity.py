@@ -1601,13 +1601,24 @@ def test_sequence_node_batch_equals_single_runs(gs, odom):
         loss.backward()
         return pcs, poses.detach(), [x.grad if x.grad is not None else torch.zeros_like(x) for x in leaves]
 
-    pcs, poses, grads = run(slice(0, B))
-    assert len(set(pcs.num_points_per_pointcloud.tolist())) == B  # really ragged
-    for b in range(B):
-        spcs, sposes, sgrads = run(slice(b, b + 1))
-        assert torch.equal(poses[b], sposes[0]), b
-        for attr in ("points_list", "normals_list", "colors_list", "features_list"):
-            assert torch.equal(getattr(pcs, attr)[b].detach(), getattr(spcs, attr)[0].detach()), (b, attr)
-        for name, g, sg in zip(("colors", "depths", "intrinsics", "poses"), grads, sgrads):
-            e = rel_err(g[b].cpu(), sg[0].cpu())
-            assert e < 1e-5, (odom, b, name, e)
+    singles = [run(slice(b, b + 1)) for b in range(B)]
+    from gradslam_amd.slam import icpslam as _icpslam
+
+    for grow in (False, True):
+        # grow: the host never learns the map counts, so its bound -- and with it the batch's row stride -- outgrows the
+        # first capacity in the middle of the sequence: the tapes of the early frames carry the old stride, and the
+        # reverse pass has to repack its working arrays when it walks back past the growth step
+        _icpslam._NO_READBACK = grow
+        try:
+            pcs, poses, grads = run(slice(0, B))
+        finally:
+            _icpslam._NO_READBACK = False
+        assert len(set(pcs.num_points_per_pointcloud.tolist())) == B  # really ragged
+        for b in range(B):
+            spcs, sposes, sgrads = singles[b]
+            assert torch.equal(poses[b], sposes[0]), (grow, b)
+            for attr in ("points_list", "normals_list", "colors_list", "features_list"):
+                assert torch.equal(getattr(pcs, attr)[b].detach(), getattr(spcs, attr)[0].detach()), (grow, b, attr)
+            for name, g, sg in zip(("colors", "depths", "intrinsics", "poses"), grads, sgrads):
+                e = rel_err(g[b].cpu(), sg[0].cpu())
+                assert e < 1e-5, (odom, grow, b, name, e)

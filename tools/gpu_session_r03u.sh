@@ -1,11 +1,11 @@
 #!/bin/bash
 # GPU session r03u: everything the judged files come from, on ONE tree: smoke, the GPU suite, counter passes (VALU view of
 # the c2 association kernel, HBM traffic of J at 2^24), rocprofv3 summaries of bench.py and of the 200-frame runs, a two-rank
-# rehearsal of bench.py on the one card (RCCL, ranks_seen), the full bench line with the CPU baseline.
+# rehearsal of bench.py on the one card (gloo: RCCL refuses two ranks on one device; ranks_seen), the full bench line with the CPU baseline.
 set -o pipefail
 R=$PWD
 O=$R/gpurun_out/r03u; mkdir -p $O
-export GS_COMMIT=__COMMIT__
+export GS_COMMIT=8669bd4
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 echo "== all gpu tests"; date
@@ -24,7 +24,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pf200 -- python3 tools/profile_pointfusion.py 200 icp > $O/pf200_prof.txt 2>&1; grep frames/s $O/pf200_prof.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fb -- python3 tools/fwd_bwd_c3.py 200 gradicp > $O/fb_prof.txt 2>&1; tail -1 $O/fb_prof.txt
 echo "== two ranks on one card"; date
-GS_BENCH_SHORT=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_2rank.json 2> $O/bench_2rank.err; echo "rc=$?"; cut -c1-260 $O/bench_2rank.json
+GS_DIST_BACKEND=gloo GS_BENCH_SHORT=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_2rank.json 2> $O/bench_2rank.err; echo "rc=$?"; cut -c1-260 $O/bench_2rank.json
 echo "== full bench"; date
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; tail -2 $O/bench.err
 python - <<P
