@@ -1308,18 +1308,6 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         return;
     }
     constexpr bool grid = GRID;  // (the host launches this variant only with complete hints and camera)
-    // GRID: waves 0 .. RW-1 sum the partial rows of the folded step (wave 0 then runs the step), waves SW .. 15 stage the
-    // windows, wave SW with the per-lane extras.  The two groups never meet at a block barrier before the one that closes the
-    // prologue: the row sums are handed to wave 0 through LDS flags, so the staging starts at kernel entry instead of
-    // behind reduce_partials' two barriers (~3 us: phase stamps r03l -- centre known 3.4 us after entry, step done at 4.5,
-    // staging at 6.8, barrier at 7.8).  The sums are reduce_partials' bit for bit: same rows per group, same order.
-    constexpr int RW = GRID ? 4 : 16, SW = GRID ? 4 : 1;
-    __shared__ float rp_stage[32][33];
-    __shared__ int rp_flag[4];
-    if (GRID) {
-        if (threadIdx.x < 4) rp_flag[threadIdx.x] = 0;
-        __syncthreads();  // (at kernel entry: every wave is here within a fraction of a microsecond)
-    }
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
     // GRID: what the staging waves need first -- the lane's own pixel, the pixel its point projects to (previous launch's
     // cells / the caller's cloud), wave 1's seed keys and its copy of the camera constants -- is REQUESTED here, before the
@@ -1329,19 +1317,19 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     int e_h = 0, e_c = -1, e_cam = 0;
     f3 e_pp{0.0f, 0.0f, 0.0f};
     unsigned long long e_ka = 0, e_kb = 0;
-    if (GRID && grid && tile_live && wave >= SW) {
+    if (GRID && grid && tile_live && wave != 0) {
         if (ok) {
             e_h = C->hints.src_pix[i];
             if (C->cam_ok) {
                 if (first) e_pp = ld3(C->user_src, i);
                 else e_c = C->cells[(1 - par) * C->cells_stride + i];
             }
-            if (wave == SW && !first) {
+            if (wave == 1 && !first) {
                 const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
                 e_ka = B.N(ba)[i]; e_kb = B.N(bb)[i];
             }
         }
-        if (wave == SW && lane < (int)(sizeof(CamK) / 4)) e_cam = reinterpret_cast<const int *>(&C->cam)[lane];
+        if (wave == 1 && lane < (int)(sizeof(CamK) / 4)) e_cam = reinterpret_cast<const int *>(&C->cam)[lane];
     }
 
     // ---- the O(1) step is wave 0's; GRID: the other fifteen waves meanwhile work out the window of every lane and the
@@ -1349,48 +1337,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     // Nothing of that depends on the step, so it costs the association no time.
     if (step_mode >= 0) {
         // (rows of surplus blocks -- see above -- are zeros behind every thread's last live row: not read)
-        const int nrows = min(nblocks_in, (ns + C->tile_points - 1) / C->tile_points);
-        if (GRID) {
-            if (wave < RW) {
-                // reduce_partials' thread (g, k) sums rows g, g + 32, g + 64, ... of accumulator k; here thread (g8, k) keeps
-                // the four sums of g = g8, g8 + 8, g8 + 16, g8 + 24 -- the same additions in the same order
-                const int k = threadIdx.x & 31, g8 = threadIdx.x >> 5;
-                constexpr int U = 10;  // rows per group and round in flight (4 x 10 loads per thread: 1 280 rows per round; a 160 x 120 ds-grid has 300)
-                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                for (int b0 = 0; b0 < nrows; b0 += 32 * U) {
-                    float a[4][U];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int b = b0 + g8 + 8 * j + 32 * u;
-                            a[j][u] = (k < NACC && b < nrows) ? partials_in[b * NACC + k] : 0.0f;
-                        }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int u = 0; u < U; ++u) v[j] += a[j][u];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rp_stage[k][g8 + 8 * j] = v[j];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(&rp_flag[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (wave == 0) {
-                for (int w = 1; w < RW; ++w)
-                    while (__hip_atomic_load(&rp_flag[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (lane < NACC) {
-                    float t = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 32; ++q) t += rp_stage[lane][q];
-                    acc_sm[lane] = t;
-                }
-                wave_sync();
-            }
-        } else {
-            reduce_partials(partials_in, nrows, acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
-        }
+        reduce_partials(partials_in, min(nblocks_in, (ns + C->tile_points - 1) / C->tile_points), acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
         // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
         if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
     }
@@ -1410,7 +1357,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             *reinterpret_cast<float4 *>(sh.seed[0][lane]) = make_float4(qa.x, qa.y, qa.z, __int_as_float(sa));
             *reinterpret_cast<float4 *>(sh.seed[1][lane]) = make_float4(qb.x, qb.y, qb.z, __int_as_float(sb));
         }
-    } else if (grid && tile_live && wave >= SW) {
+    } else if (grid && tile_live) {
         const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
         const int h = ok ? min(max(e_h, 0), nc - 1) : 0;
         // Window centre: the grid pixel the point projects to.  The point itself is only known once the step (wave 0,
@@ -1426,7 +1373,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         int row_lo[WROWS], row_hi[WROWS];
 #pragma unroll
         for (int r = 0; r < WROWS; ++r) { row_lo[r] = 0; row_hi[r] = 0; }
-        if (wave == SW) {
+        if (wave == 1) {
 #pragma unroll
             for (int r = 0; r < WROWS; ++r) {
                 const int g = c + (r - 1) * Wd;
@@ -1435,7 +1382,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             }
         }
         float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-        if (wave == SW && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
+        if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
             int sj[2];
             if (first) {
                 const int slot = min(max(C->hints.pix_start[h], 0), nt - 1);
@@ -1512,11 +1459,11 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         }
         GS_STAMP(14);
         // staging loads first (they are the long ones), the per-lane rows behind them
-        constexpr int ST = KNN_BT - 64 * SW, NR = (POOL + ST - 1) / ST;
+        constexpr int ST = KNN_BT - 64, NR = (POOL + ST - 1) / ST;
         float4 sreg[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int e = (int)threadIdx.x - 64 * SW + ST * r;
+            const int e = (int)threadIdx.x - 64 + ST * r;
             if (e < used) {
                 int bb = 0, bo = 0;  // the staged band that holds pool element e: the last one that starts at or before it
 #pragma unroll
@@ -1529,7 +1476,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 sreg[r] = make_float4(q3.x, q3.y, q3.z, __int_as_float(C->hints.scan_orig[slot]));
             }
         }
-        if (wave == SW) {
+        if (wave == 1) {
             bool full = in;
 #pragma unroll
             for (int r = 0; r < WROWS; ++r) {
@@ -1566,7 +1513,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int e = (int)threadIdx.x - 64 * SW + ST * r;
+            const int e = (int)threadIdx.x - 64 + ST * r;
             if (e < used) *reinterpret_cast<float4 *>(&sh.u.stage[4 * e]) = sreg[r];
         }
         GS_STAMP(15);
