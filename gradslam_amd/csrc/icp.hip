@@ -203,6 +203,8 @@ struct KnnShared {
     int centre[64];            // per lane: the window's centre pixel
     CamK cam;                  // the bucketing camera (copied once per block: the proof reads it at LDS, not scalar-cache, latency)
     int band[2 * WBANDS + 1];  // staged bands: first slot x WBANDS, pool offset x WBANDS, pool fill
+    int plan[2 * WBANDS];      // per band: its pool offset if it is in the pool and not empty, else INT_MAX | its length (for the staging waves)
+    unsigned int plan_ready;   // set (release) by the planning wave once band / plan are written
     float seed[2][64][4];      // the seed for either outcome of the step: target point, reference index bits
     union alignas(16) {
         struct {
@@ -760,35 +762,29 @@ __global__ __launch_bounds__(LIN_T) void linearize_k(const float *__restrict__ s
 // thread (g, k) = (t / 32, t % 32) sums rows g, g+32, g+64, ... of accumulator k (coalesced over k),
 // then 29 threads add the 32 group sums in order.  Two short LDS stages, no shuffle chains.
 constexpr int RP_LOADS = 16;  // reduce_partials: loads in flight per thread
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-// `after_issue` runs once, right after the first round of loads has been issued and before it is consumed: the
-// place for loads that should be in flight at the same time without delaying these (the grid search's staging).
-template <class Hook = NoHook>
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm,
-                                                Hook after_issue = Hook()) {
+constexpr int RP_FEW = 10;    // knn1_loop_k for launches of at most 32 * RP_FEW blocks (a 160 x 120 frame: 300): every instruction of its
+                              // prologue is executed by sixteen waves on four SIMDs
+// The two halves of one round, for a caller that has other loads to put in flight between them (knn1_loop_k: a launch of at
+// most 32 * RP_LOADS = 512 rows is ONE round): rp_issue requests thread (g, k)'s rows, rp_finish sums them in the order below.
+template <int NL = RP_LOADS>
+__device__ __forceinline__ void rp_issue(const float *__restrict__ partials, int nblocks, int b0, float (&a)[RP_LOADS]) {
+    // Clamped addresses, unconditional loads; rp_sum masks what lies outside.  (A select -- or a branch -- at the load makes
+    // the compiler wait for each value where it is requested: sixteen trips in a row instead of one.)
+    // NL < RP_LOADS: the caller knows that nblocks <= 32 NL (the rows beyond are zeros in either form: same sums).
+    const int kc = min((int)(threadIdx.x & 31), NACC - 1), last = max(nblocks - 1, 0);
+#pragma unroll
+    for (int u = 0; u < RP_LOADS; ++u) a[u] = u < NL ? partials[min(b0 + 32 * u, last) * NACC + kc] : 0.0f;
+}
+template <int NL = RP_LOADS>
+__device__ __forceinline__ float rp_sum(const float (&a)[RP_LOADS], int nblocks, int b0, float v) {
+    const int k = threadIdx.x & 31;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) v += (k < NACC && b0 + 32 * u < nblocks) ? a[u] : 0.0f;
+    return v;
+}
+__device__ __forceinline__ void rp_finish(float v, float *acc_sm) {
     __shared__ float stage[32][33];
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // blockDim.x == 1024 -> g in [0, 32)
-    float v = 0.0f;
-    {
-        // The rows were written by the previous launch on other CUs: every read is a trip to memory-side
-        // cache (~1.5 us), so what matters is how many of them are in flight -- sixteen per thread and round: the 512
-        // rows of a full chip (two tiles per CU) in ONE round.
-        bool hooked = false;
-        for (int b0 = g; b0 < nblocks || !hooked; b0 += 32 * RP_LOADS) {
-            float a[RP_LOADS];
-#pragma unroll
-            for (int u = 0; u < RP_LOADS; ++u) {
-                const int b = b0 + 32 * u;
-                a[u] = (k < NACC && b < nblocks) ? partials[b * NACC + k] : 0.0f;
-            }
-            if (!hooked) after_issue();
-            hooked = true;
-#pragma unroll
-            for (int u = 0; u < RP_LOADS; ++u) v += a[u];
-        }
-    }
     stage[k][g] = v;
     __syncthreads();
     if (threadIdx.x < NACC) {
@@ -798,6 +794,40 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
         acc_sm[threadIdx.x] = t;
     }
     __syncthreads();
+}
+// rp_finish for a block in which only wave 0 needs the sums (knn1_loop_k<true>: the other fifteen waves stage the search's
+// windows meanwhile, and the two block barriers above kept them from starting for 1.2 us -- phase stamps, r04a).  Every
+// wave leaves its 128 sums in LDS, waits for its OWN LDS writes (the caller's state words among them) and counts itself in;
+// wave 0 waits for the count, then adds the 32 group sums in the same order as rp_finish.  `cnt` must be zero and visible
+// to all waves before the first of them gets here (the caller's raw barrier at kernel start).
+__device__ __forceinline__ void rp_finish_wave0(float v, float *acc_sm, unsigned int *cnt) {
+    __shared__ float stage[32][33];
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    stage[k][g] = v;
+    if (threadIdx.x >= 64) {
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned int)(KNN_NW - 1)) __builtin_amdgcn_s_sleep(1);
+        if (threadIdx.x < NACC) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) t += stage[threadIdx.x][q];
+            acc_sm[threadIdx.x] = t;
+        }
+    }
+}
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partials, int nblocks, float *acc_sm) {
+    const int g = threadIdx.x >> 5;
+    float v = 0.0f;
+    // The rows were written by the previous launch on other CUs: every read is a trip to memory-side
+    // cache (~1.5 us), so what matters is how many of them are in flight -- sixteen per thread and round: the 512
+    // rows of a full chip (two tiles per CU) in ONE round.
+    for (int b0 = g; b0 < nblocks; b0 += 32 * RP_LOADS) {
+        float a[RP_LOADS];
+        rp_issue(partials, nblocks, b0, a);
+        v = rp_sum(a, nblocks, b0, v);
+    }
+    rp_finish(v, acc_sm);
 }
 
 // H (6x6 symmetric) | g | e | cnt from the 29 accumulators
@@ -1282,11 +1312,13 @@ __device__ __forceinline__ float cam_bound2(const CamK &k, const f3 s, const int
     return L > 0.0f ? L * L : 0.0f;  // (NaN compares false: no proof)
 }
 
-template <bool GRID>
-__global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
+template <bool GRID, int NL>
+__global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *__restrict__ C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
                                                          const float *__restrict__ partials_in, int nblocks_in, int step_mode,
                                                          int look_slot, float *__restrict__ rec, int phase /* first | launch parity << 1 */,
-                                                         int out_slot, LoopBufs B, float *__restrict__ partials /* gridDim.x x NACC */) {
+                                                         int out_slot, LoopBufs B, float *__restrict__ partials /* gridDim.x x NACC */,
+                                                         const int32_t *__restrict__ pix_ws, const int32_t *__restrict__ cells_in, int cap,
+                                                         int tile_points, const float *__restrict__ user_src) {
     const int first = phase & 1, par = phase >> 1;
     __shared__ KnnShared sh;
     __shared__ IcpState st_sm;
@@ -1295,56 +1327,97 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
     constexpr int kWords = sizeof(IcpState) / 4;
     GS_STAMP(6);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ns = C->ns, nt = C->nt;
-    const int tile0 = blockIdx.x * C->tile_points;
+    const int tile0 = blockIdx.x * tile_points;
     const int i = tile0 + lane;
-    const bool ok = lane < C->tile_points && i < ns;
+    constexpr bool grid = GRID;  // (the host launches this variant only with complete hints and camera)
+    // ---- Everything whose address follows from the kernel's ARGUMENTS is requested here, in one go, before anything is
+    // waited for: the state, the partial rows of the folded step, and (GRID) what the staging waves need first -- the
+    // lane's own pixel (the workspace's copy of hints.src_pix: pix_ws), the pixel its point projected to in the previous
+    // launch (cells_in), wave 2's seed keys and its copy of the camera constants.  Every trip to memory at kernel start costs
+    // 1.5-2 us (the data was written by other XCDs' CUs).  Until round 3's last session these requests stood behind the
+    // loop constants (C->ns for the bounds, C->hints.* / C->cells for the addresses: a trip of their own), the state's load
+    // was waited for on the spot (another, in waves 0 and 1), and the pointers taken from the constants made FLAT loads,
+    // which every later wait for a scalar load also waits for (the compiler's s_waitcnt vmcnt(0) lgkmcnt(0)): four trips in
+    // a row before the first window centre was known (phase stamps: 3.2 us after kernel entry).  Now the indices are
+    // clamped to the arrays' capacity (cap: all of them are the workspace's own, sized by it) instead of tested against ns.
+    // No branch stands between these requests and nothing is tested on them before all are out: the compiler places a load
+    // where its scheduling region first needs it, and sinks a load below a branch whose other side does not use it -- with the
+    // block's early exit tested first, every request stood behind the trip for ns again.  Hence: addresses nobody needs are
+    // clamped to something harmless instead of branched around; ns / nt come by a VECTOR load (lane & 1 picks) in the same
+    // batch instead of the scalar load the compiler would issue only where the exit test wants it; and the empty asm below
+    // names every requested value, so that none of the requests can move past it.
+    __shared__ unsigned int rp_cnt;  // GRID: waves whose part of the row sums (and of the state) is in LDS (rp_finish_wave0)
+    if constexpr (GRID) {
+        // rp_cnt = 0 must be visible to every wave before any of them counts itself in: wave 0 waits for its LDS write, and
+        // all meet at a RAW barrier (no fence needed, nothing else is in flight yet; at kernel start the waves of a block
+        // arrive within ~0.1 us of each other)
+        if (threadIdx.x == 0) { rp_cnt = 0; sh.plan_ready = 0; }
+        if (wave == 0) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    }
+    const int ic = min(i, cap - 1);
+    const int st_w = reinterpret_cast<const int *>(S_in)[min((int)threadIdx.x, kWords - 1)];
+    float rp_a[RP_LOADS];
+    // (consumed only if a step is folded in: then the launch has <= 512 blocks, one round; ten loads cover the 300 rows of a
+    // 160 x 120 frame -- every instruction here is executed by sixteen waves on four SIMDs)
+    // (NL: the host instantiates the ten-load form for launches of <= 320 blocks)
+    rp_issue<NL>(partials_in, nblocks_in, (int)(threadIdx.x >> 5), rp_a);
+    static_assert(offsetof(LoopConst, nt) == offsetof(LoopConst, ns) + 4, "ns | nt are read as a pair");
+    const int nn = reinterpret_cast<const int *>(&C->ns)[lane & 1];
+    int e_h = 0, e_c = -1, e_cam = 0;
+    unsigned long long e_k0 = 0, e_k1 = 0;
+    if constexpr (GRID) {
+        e_h = pix_ws[ic];
+        e_c = cells_in[ic];
+        // wave 2's seeds for either outcome of the step: outside tape mode the two neighbour arrays are slots 0 and 1 (which
+        // of them is current is decided below, when the state has arrived); tape mode names the slots in the state
+        const int ik = wave == 2 ? ic : 0;
+        e_k0 = B.N(0)[ik]; e_k1 = B.N(1)[ik];
+        e_cam = reinterpret_cast<const int *>(&C->cam)[min(lane, (int)(sizeof(CamK) / 4) - 1)];
+        asm volatile("" ::"v"(e_h), "v"(e_c), "v"(e_cam), "v"((unsigned)e_k0), "v"((unsigned)(e_k0 >> 32)),
+                     "v"((unsigned)e_k1), "v"((unsigned)(e_k1 >> 32)));
+    }
+    asm volatile("" ::"v"(st_w), "v"(nn), "v"(rp_a[0]), "v"(rp_a[1]), "v"(rp_a[2]), "v"(rp_a[3]), "v"(rp_a[4]), "v"(rp_a[5]), "v"(rp_a[6]),
+                 "v"(rp_a[7]), "v"(rp_a[8]), "v"(rp_a[9]), "v"(rp_a[10]), "v"(rp_a[11]), "v"(rp_a[12]), "v"(rp_a[13]), "v"(rp_a[14]),
+                 "v"(rp_a[15]));
+    GS_STAMP(8);  // (diagnostic build: the first batch has arrived)
+    const int ns = __builtin_amdgcn_readlane(nn, 0), nt = __builtin_amdgcn_readlane(nn, 1);
+    const bool ok = lane < tile_points && i < ns;
     const bool tile_live = tile0 < ns && nt > 0;
-    // The launch covers the cloud's CAPACITY; blocks beyond its actual size leave at once.  Their partial rows are zeros at
-    // the END of every thread's summation sequence in reduce_partials (not even read).  (Block 0 publishes the state: it
-    // always stays.)
+    // The launch covers the cloud's CAPACITY; blocks beyond its actual size leave at once.  Their partial rows are zeros
+    // (added behind every thread's live rows by the next launch: x + 0 = x).  (Block 0 publishes the state: it always stays.)
     if (tile0 >= ns && blockIdx.x != 0) {
         if (threadIdx.x < NACC) partials[blockIdx.x * NACC + threadIdx.x] = 0.0f;
         return;
     }
-    constexpr bool grid = GRID;  // (the host launches this variant only with complete hints and camera)
-    if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
-    // GRID: what the staging waves need first -- the lane's own pixel, the pixel its point projects to (previous launch's
-    // cells / the caller's cloud), wave 1's seed keys and its copy of the camera constants -- is REQUESTED here, before the
-    // partial rows of the folded step: every trip to memory at kernel start costs ~2 us (the data was written by other
-    // XCDs' CUs), and these then share one trip with the rows instead of following it (phase stamps, r03h: the centre was
-    // known 4.1 us after kernel entry, the barrier behind the staging fell at 10.7 us)
-    int e_h = 0, e_c = -1, e_cam = 0;
     f3 e_pp{0.0f, 0.0f, 0.0f};
     unsigned long long e_ka = 0, e_kb = 0;
-    if (GRID && grid && tile_live && wave != 0) {
-        if (ok) {
-            e_h = C->hints.src_pix[i];
-            if (C->cam_ok) {
-                if (first) e_pp = ld3(C->user_src, i);
-                else e_c = C->cells[(1 - par) * C->cells_stride + i];
-            }
-            if (wave == 1 && !first) {
-                const int ba = S_in->b_cur, bb = look_slot >= 0 ? look_slot : 1 - ba;
-                e_ka = B.N(ba)[i]; e_kb = B.N(bb)[i];
-            }
+    if (GRID && grid && tile_live && wave != 0 && ok) {
+        if (first && C->cam_ok) e_pp = ld3(user_src, i);  // (the first launch: no step is folded into it)
+        if (wave == 2 && !first) {
+            const int ba = S_in->b_cur;
+            if (look_slot < 0) { e_ka = ba == 0 ? e_k0 : e_k1; e_kb = ba == 0 ? e_k1 : e_k0; }
+            else { e_ka = B.N(ba)[i]; e_kb = B.N(look_slot)[i]; }
         }
-        if (wave == 1 && lane < (int)(sizeof(CamK) / 4)) e_cam = reinterpret_cast<const int *>(&C->cam)[lane];
     }
 
     // ---- the O(1) step is wave 0's; GRID: the other fifteen waves meanwhile work out the window of every lane and the
     // row bands of the tile, stage the bands' targets into LDS and fetch the seed for either outcome of the step.
     // Nothing of that depends on the step, so it costs the association no time.
+    if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = st_w;
     if (step_mode >= 0) {
-        // (rows of surplus blocks -- see above -- are zeros behind every thread's last live row: not read)
-        reduce_partials(partials_in, min(nblocks_in, (ns + C->tile_points - 1) / C->tile_points), acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
+        const float v = rp_sum<NL>(rp_a, nblocks_in, (int)(threadIdx.x >> 5), 0.0f);
+        if constexpr (GRID) rp_finish_wave0(v, acc_sm, &rp_cnt);  // wave 0 leaves it with acc_sm and every wave's st_sm words visible TO IT
+        else rp_finish(v, acc_sm);                                // ends with a barrier: st_sm and acc_sm are visible
+        GS_STAMP(9);  // (diagnostic build: the rows are summed)
         // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
-        if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(S_in)[threadIdx.x];
+        if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = st_w;
     }
     if (wave == 0) {
         const bool pub = blockIdx.x == 0;  // the one block whose copy of the new state is published
         if (step_mode >= 0)
             step_wave0(&st_sm, acc_sm, step_mode, C->gp, pub ? C->trace : nullptr, pub ? C->out_T : nullptr, look_slot, pub ? rec : nullptr, lu_sm, true);
+        GS_STAMP(10);  // (wave 0: the step is done)
     } else if (!grid && tile_live && !first && wave == 1) {
         // chunk-box search: the seed (the previous neighbour's target point) for either outcome of the step, fetched
         // while wave 0 computes it -- two dependent loads less on the association's critical path
@@ -1358,104 +1431,142 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
             *reinterpret_cast<float4 *>(sh.seed[1][lane]) = make_float4(qb.x, qb.y, qb.z, __int_as_float(sb));
         }
     } else if (grid && tile_live) {
+        // Three roles.  Wave 1 PLANS: every lane's window centre, the displacement of the tile's majority, the tile's row
+        // bands and (one trip) their slot ranges -> LDS, then a flag.  Wave 2 prepares the LANES: the seeds for either
+        // outcome of the step and each lane's own window rows (its loads leave at once; the rows are packed against the plan
+        // when it is there).  The other thirteen sleep until the plan is in LDS; then all fifteen stage the bands' targets.
+        // Every staging wave used to derive the same plan for itself -- ~200 instructions x 15 waves on four SIMDs: the
+        // issue slots, not the memory trips, were what the phase stamps showed between "first batch arrived" and "centre
+        // known" (1.6 us, r04a) -- and wave 1 carried the seeds and rows on top of the plan.
         const int Wd = C->hints.grid_w, nc = C->hints.grid_w * C->hints.grid_h;
-        const int h = ok ? min(max(e_h, 0), nc - 1) : 0;
+        constexpr int R = 1;
+        int bbase[WBANDS], pstart[WBANDS], bcnt[WBANDS], used = 0;  // per band: first slot, pool offset (INT_MAX: not in the pool), length; pool fill
+#pragma unroll
+        for (int q = 0; q < WBANDS; ++q) { bbase[q] = 0; pstart[q] = 0x7fffffff; bcnt[q] = 0; }
         // Window centre: the grid pixel the point projects to.  The point itself is only known once the step (wave 0,
         // concurrently) has produced dT -- but it is within millimetres of the cloud the PREVIOUS launch wrote, whatever
         // the step decides, and that launch left the pixel of every point it wrote in C->cells (by launch parity: one
         // load at an address known at kernel start; first launch: the caller's cloud under the initial transform,
         // exactly).  The centre only selects which window is examined; the proof below is evaluated for the point's
         // actual position against it.
+        const int h = ok ? min(max(e_h, 0), nc - 1) : 0;
         int c = h;
-        if (ok && C->cam_ok) c = first ? cam_cell(C->cam, xform(S_in->dT, e_pp)) : min(max(e_c, 0), nc - 1);
-        // wave 1: the first / one-past-last slots of the lane's three window rows -- requested as soon as the centre is known,
-        // ahead of the tile's reductions and band loads (they used to leave last and the block's barrier waited for them)
+        if (wave <= 2 && ok && C->cam_ok) c = first ? cam_cell(C->cam, xform(S_in->dT, e_pp)) : min(max(e_c, 0), nc - 1);
         int row_lo[WROWS], row_hi[WROWS];
+        float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
 #pragma unroll
         for (int r = 0; r < WROWS; ++r) { row_lo[r] = 0; row_hi[r] = 0; }
-        if (wave == 1) {
+        if (wave == 2) {
+            // the first / one-past-last slots of the lane's three window rows, and the seeds (the step leaves b_cur as it is or
+            // moves it to the look-ahead's array): requested now, used when the plan is there
 #pragma unroll
             for (int r = 0; r < WROWS; ++r) {
                 const int g = c + (r - 1) * Wd;
                 row_lo[r] = C->hints.pix_start[min(max(g - 1, 0), nc - 1)];
                 row_hi[r] = C->hints.pix_start[min(max(g + 1, 0), nc - 1) + 1];
             }
-        }
-        float4 sd[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-        if (wave == 1 && ok) {  // seeds: the step leaves b_cur as it is or moves it to the look-ahead's array
-            int sj[2];
-            if (first) {
-                const int slot = min(max(C->hints.pix_start[h], 0), nt - 1);
-                sj[0] = sj[1] = min(max(C->hints.scan_orig[slot], 0), nt - 1);
-            } else {
-                // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
-                sj[0] = (int)min((uint32_t)(e_ka & 0xffffffffu), (uint32_t)(nt - 1));
-                sj[1] = (int)min((uint32_t)(e_kb & 0xffffffffu), (uint32_t)(nt - 1));
-            }
+            if (ok) {
+                int sj[2];
+                if (first) {
+                    const int slot = min(max(C->hints.pix_start[h], 0), nt - 1);
+                    sj[0] = sj[1] = min(max(C->hints.scan_orig[slot], 0), nt - 1);
+                } else {
+                    // (one of the two arrays may never have been written -- the outcome that cannot happen: clamp as unsigned)
+                    sj[0] = (int)min((uint32_t)(e_ka & 0xffffffffu), (uint32_t)(nt - 1));
+                    sj[1] = (int)min((uint32_t)(e_kb & 0xffffffffu), (uint32_t)(nt - 1));
+                }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const f3 q = ld3(C->tgt, sj[u]);
-                sd[u] = make_float4(q.x, q.y, q.z, __int_as_float(sj[u]));
-            }
-        }
-        // The lanes of a tile move together: their centres are their own pixels (consecutive in row-major order, also
-        // across a row end) plus nearly the same displacement.  Relative to the tile's smallest displacement a lane
-        // sits up to a pixel further along the row and / or one row further down (rel); what remains is contiguous
-        // in row-major order again, so every row band of the tile is ONE slot range.
-        // (wave reductions leave uniform values in vector registers: move them, and all that follows, to scalars)
-        // The reference displacement is the MAJORITY's: a lane whose neighbour is far away (no map point near it) has a
-        // centre anywhere, and taking the plain minimum would let one such lane cost the whole tile its windows.  Up to
-        // three candidates (the first lanes not yet represented); supporters = lanes within a row and three columns.
-        const int dsp = c - h;
-        auto near = [&](int r) { return abs(r) <= 3 || abs(r - Wd) <= 3 || abs(r + Wd) <= 3; };
-        const unsigned long long okm = __ballot(ok);
-        unsigned long long pool = okm, sup = 0;
-        for (int tries = 0; tries < 3 && pool; ++tries) {
-            const int cand = __builtin_amdgcn_readlane(dsp, __builtin_ctzll(pool));
-            const unsigned long long m = __ballot(ok && near(dsp - cand));
-            if (__popcll(m) > __popcll(sup)) sup = m;
-            if (2 * __popcll(m) >= __popcll(okm)) break;
-            pool &= ~m;
-        }
-        GS_STAMP(13);
-        const bool mine = ok && ((sup >> lane) & 1);
-        const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i(mine ? dsp : 0x7fffffff));
-        const int e = mine ? dsp - dmin : 0;
-        int rel = mine ? (e >= Wd / 2) + (e >= Wd + Wd / 2) : 2;  // rel > 1: no window (a lane that does not move with its tile)
-        const bool in = mine && rel <= 1 && abs(e - rel * Wd) <= 6;
-        if (!in) rel = 2;
-        const int beta = c - rel * Wd;
-        const int bmin = __builtin_amdgcn_readfirstlane(wave_min_i(in ? beta : 0x7fffffff));
-        const int bmax = __builtin_amdgcn_readfirstlane(wave_max_i(in ? beta : (int)0x80000000));
-        const bool two_rows = __any(in && rel == 1);
-        // Band kk covers the pixels [bmin + (kk - R) Wd - R, bmax + (kk - R) Wd + R], kk = 0 .. 2 R (+ 1 if the lanes sit in
-        // two rows), R = 1 (radius 2 = five rows, six bands was measured: ~1 us per launch more on a dense target, nothing
-        // gained on a sparse one).  All first-slot loads are issued before any is used: taken one band after the other
-        // they were four dependent trips through the scalar cache (2.4 us, r03h).
-        constexpr int R = 1;
-        int bbase[WBANDS], boff[WBANDS], bcnt[WBANDS], used = 0;
-        {
-            int lo_raw[WBANDS], hi_raw[WBANDS];
-            bool want[WBANDS];
-#pragma unroll
-            for (int kk = 0; kk < WBANDS; ++kk) {
-                const int a = bmin + (kk - R) * Wd - R, b = bmax + (kk - R) * Wd + R;
-                want[kk] = kk <= 2 * R + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1;
-                lo_raw[kk] = C->hints.pix_start[min(max(a, 0), nc - 1)];
-                hi_raw[kk] = C->hints.pix_start[min(max(b, 0), nc - 1) + 1];
-            }
-#pragma unroll
-            for (int kk = 0; kk < WBANDS; ++kk) {
-                bbase[kk] = 0; bcnt[kk] = 0; boff[kk] = used;
-                const int lo = min(max(lo_raw[kk], 0), nt) & ~(CHUNK - 1);
-                const int hi = min((min(max(hi_raw[kk], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt);
-                if (want[kk] && hi > lo) {
-                    bbase[kk] = lo; bcnt[kk] = hi - lo;
-                    // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
-                    // window stays complete and with it the proof): pool offset -1
-                    if (used + (hi - lo) <= POOL) used += hi - lo; else boff[kk] = -1;
+                for (int u = 0; u < 2; ++u) {
+                    const f3 q = ld3(C->tgt, sj[u]);
+                    sd[u] = make_float4(q.x, q.y, q.z, __int_as_float(sj[u]));
                 }
             }
+        }
+        if (wave == 1) {
+            // The lanes of a tile move together: their centres are their own pixels (consecutive in row-major order, also
+            // across a row end) plus nearly the same displacement.  Relative to the tile's smallest displacement a lane
+            // sits up to a pixel further along the row and / or one row further down (rel); what remains is contiguous
+            // in row-major order again, so every row band of the tile is ONE slot range.
+            // (wave reductions leave uniform values in vector registers: move them, and all that follows, to scalars)
+            // The reference displacement is the MAJORITY's: a lane whose neighbour is far away (no map point near it) has a
+            // centre anywhere, and taking the plain minimum would let one such lane cost the whole tile its windows.  Up to
+            // three candidates (the first lanes not yet represented); supporters = lanes within a row and three columns.
+            const int dsp = c - h;
+            auto near = [&](int r) { return abs(r) <= 3 || abs(r - Wd) <= 3 || abs(r + Wd) <= 3; };
+            const unsigned long long okm = __ballot(ok);
+            unsigned long long pool = okm, sup = 0;
+            for (int tries = 0; tries < 3 && pool; ++tries) {
+                const int cand = __builtin_amdgcn_readlane(dsp, __builtin_ctzll(pool));
+                const unsigned long long m = __ballot(ok && near(dsp - cand));
+                if (__popcll(m) > __popcll(sup)) sup = m;
+                if (2 * __popcll(m) >= __popcll(okm)) break;
+                pool &= ~m;
+            }
+            GS_STAMP(13);
+            const bool mine = ok && ((sup >> lane) & 1);
+            const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i(mine ? dsp : 0x7fffffff));
+            const int e = mine ? dsp - dmin : 0;
+            int rel = mine ? (e >= Wd / 2) + (e >= Wd + Wd / 2) : 2;  // rel > 1: no window (a lane that does not move with its tile)
+            const bool in = mine && rel <= 1 && abs(e - rel * Wd) <= 6;
+            if (!in) rel = 2;
+            const int beta = c - rel * Wd;
+            const int bmin = __builtin_amdgcn_readfirstlane(wave_min_i(in ? beta : 0x7fffffff));
+            const int bmax = __builtin_amdgcn_readfirstlane(wave_max_i(in ? beta : (int)0x80000000));
+            const bool two_rows = __any(in && rel == 1);
+            // Band kk covers the pixels [bmin + (kk - R) Wd - R, bmax + (kk - R) Wd + R], kk = 0 .. 2 R (+ 1 if the lanes sit in
+            // two rows), R = 1 (radius 2 = five rows, six bands was measured: ~1 us per launch more on a dense target, nothing
+            // gained on a sparse one).  All first-slot loads are issued before any is used: taken one band after the other
+            // they were four dependent trips through the scalar cache (2.4 us, r03h).
+            int boff[WBANDS];
+            {
+                int lo_raw[WBANDS], hi_raw[WBANDS];
+                bool want[WBANDS];
+#pragma unroll
+                for (int kk = 0; kk < WBANDS; ++kk) {
+                    const int a = bmin + (kk - R) * Wd - R, b = bmax + (kk - R) * Wd + R;
+                    want[kk] = kk <= 2 * R + (two_rows ? 1 : 0) && bmax >= bmin && b >= 0 && a <= nc - 1;
+                    lo_raw[kk] = C->hints.pix_start[min(max(a, 0), nc - 1)];
+                    hi_raw[kk] = C->hints.pix_start[min(max(b, 0), nc - 1) + 1];
+                }
+                sh.centre[lane] = c;
+                sh.wflag[lane] = rel;  // (provisional: wave 2 completes it)
+#pragma unroll
+                for (int kk = 0; kk < WBANDS; ++kk) {
+                    bbase[kk] = 0; bcnt[kk] = 0; boff[kk] = used;
+                    const int lo = min(max(lo_raw[kk], 0), nt) & ~(CHUNK - 1);
+                    const int hi = min((min(max(hi_raw[kk], 0), nt) + CHUNK - 1) & ~(CHUNK - 1), nt);
+                    if (want[kk] && hi > lo) {
+                        bbase[kk] = lo; bcnt[kk] = hi - lo;
+                        // a band the pool has no room for is read from memory by the lanes themselves (slower, but the
+                        // window stays complete and with it the proof): pool offset -1
+                        if (used + (hi - lo) <= POOL) used += hi - lo; else boff[kk] = -1;
+                    }
+                }
+            }
+            // the plan: LDS, then the flag (release)
+            if (lane < WBANDS) {
+                int bb = bbase[0], bo = boff[0], bn = bcnt[0];
+#pragma unroll
+                for (int q = 1; q < WBANDS; ++q) { bb = lane == q ? bbase[q] : bb; bo = lane == q ? boff[q] : bo; bn = lane == q ? bcnt[q] : bn; }
+                sh.band[lane] = bb; sh.band[WBANDS + lane] = bo;
+                sh.plan[lane] = (bo >= 0 && bn > 0) ? bo : 0x7fffffff;
+                sh.plan[WBANDS + lane] = bn;
+            }
+            if (lane == 0) { sh.band[2 * WBANDS] = used; sh.cnt = 0; }
+            sh.key[lane] = KEY_NONE;
+            if (lane == 0) __hip_atomic_store(&sh.plan_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int q = 0; q < WBANDS; ++q) pstart[q] = (boff[q] >= 0 && bcnt[q] > 0) ? boff[q] : 0x7fffffff;
+        } else {
+            while (__hip_atomic_load(&sh.plan_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(2);
+            const int pl = sh.band[min(lane, 2 * WBANDS)], ps = sh.plan[min(lane, 2 * WBANDS - 1)];
+#pragma unroll
+            for (int q = 0; q < WBANDS; ++q) {
+                bbase[q] = __builtin_amdgcn_readlane(pl, q);
+                pstart[q] = __builtin_amdgcn_readlane(ps, q);
+                bcnt[q] = __builtin_amdgcn_readlane(ps, WBANDS + q);
+            }
+            used = __builtin_amdgcn_readlane(pl, 2 * WBANDS);
         }
         GS_STAMP(14);
         // staging loads first (they are the long ones), the per-lane rows behind them
@@ -1468,15 +1579,17 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 int bb = 0, bo = 0;  // the staged band that holds pool element e: the last one that starts at or before it
 #pragma unroll
                 for (int q = 0; q < WBANDS; ++q) {
-                    const bool here = boff[q] >= 0 && bcnt[q] > 0 && e >= boff[q];
-                    bb = here ? bbase[q] : bb; bo = here ? boff[q] : bo;
+                    const bool here = e >= pstart[q];
+                    bb = here ? bbase[q] : bb; bo = here ? pstart[q] : bo;
                 }
                 const int slot = bb + e - bo;
                 const f3 q3 = ld3(C->hints.scan_points, slot);
                 sreg[r] = make_float4(q3.x, q3.y, q3.z, __int_as_float(C->hints.scan_orig[slot]));
             }
         }
-        if (wave == 1) {
+        if (wave == 2) {
+            const int rel = sh.wflag[lane];  // (the planner's; its centre is this wave's own c: same arithmetic on the same words)
+            const bool in = rel <= 1;
             bool full = in;
 #pragma unroll
             for (int r = 0; r < WROWS; ++r) {
@@ -1498,16 +1611,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
                 sh.win[r][lane] = packed;
             }
             sh.wflag[lane] = min(rel, 2) | (full ? 4 : 0) | (R << 3);
-            sh.centre[lane] = c;
             if (lane < (int)(sizeof(CamK) / 4)) reinterpret_cast<int *>(&sh.cam)[lane] = e_cam;
-            sh.key[lane] = KEY_NONE;
-            if (lane == 0) { sh.cnt = 0; sh.band[2 * WBANDS] = used; }
-            if (lane < WBANDS) {
-                int bb = bbase[0], bo = boff[0];
-#pragma unroll
-                for (int q = 1; q < WBANDS; ++q) { bb = lane == q ? bbase[q] : bb; bo = lane == q ? boff[q] : bo; }
-                sh.band[lane] = bb; sh.band[WBANDS + lane] = bo;
-            }
             *reinterpret_cast<float4 *>(sh.seed[0][lane]) = sd[0];
             *reinterpret_cast<float4 *>(sh.seed[1][lane]) = sd[1];
         }
@@ -1531,7 +1635,7 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         return;
     }
     const int p_cur = S->p_cur, b_cur = S->b_cur;
-    const float *in = first ? C->user_src : B.P(p_cur);
+    const float *in = first ? user_src : B.P(p_cur);
     float *out = B.P(out_slot >= 0 ? out_slot : 1 - p_cur);
     unsigned long long *best = B.N(out_slot >= 0 ? out_slot : 1 - b_cur);
     f3 s{0.0f, 0.0f, 0.0f};
@@ -1611,6 +1715,9 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *C, con
         GS_STAMP(2);
         key = ok ? sh.key[lane] : KEY_NONE;
         GS_STAMP(3);
+        // diagnostic build: which CU the block ran on (slot 5 as knn_prune_search writes it; a proven tile never gets there)
+        GS_COUNT(5, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
+                        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 48));
     } else {
         int sj = -1;
         if (!first) {  // seeded from what wave 1 fetched during the step (knn_tile's -2: keys already in LDS)
@@ -1690,6 +1797,14 @@ __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, cons
             if (lc.tile_points != 64) atomicAdd(&g_loop_counts[2], 1u);
         }
         reinterpret_cast<int *>(lc_out)[threadIdx.x] = v;
+    }
+    // the loop's own copy of hints.src_pix, defined up to the cloud's capacity: the association kernel requests it at kernel
+    // start by an index clamped to the capacity, before it knows ns (knn1_loop_k)
+    if (lc.cells) {
+        const int n = *lc.d_ns;
+        int32_t *pix = lc.cells + 2 * (size_t)lc.cells_stride;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < lc.cells_stride; i += gridDim.x * blockDim.x)
+            pix[i] = (i < n && lc.hints.src_pix) ? lc.hints.src_pix[i] : 0;
     }
     if (blockIdx.x == 0) {  // the bucketing camera, after the plain copy above (same words)
         __syncthreads();
@@ -1844,7 +1959,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
     const size_t oPart = take((size_t)loop_blocks_max(max_ns) * NACC * 4), oPart1 = take((size_t)loop_blocks_max(max_ns) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt)), oSBox = take((size_t)cdiv(max_nt > 0 ? max_nt : 1, 1024) * 6 * 4);
-    const size_t oLc = take(sizeof(LoopConst)), oCells = take((size_t)max_ns * 8);
+    const size_t oLc = take(sizeof(LoopConst)), oCells = take((size_t)max_ns * 12);  // cells by launch parity (2 planes) | the loop's copy of hints.src_pix
     if (ws && out) {
         char *p = (char *)ws;
         out->S[0] = (IcpState *)(p + oS); out->S[1] = (IcpState *)(p + oS1);
@@ -1960,14 +2075,21 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         const int nxt = pending >= 0 ? 1 - cur : cur;  // a folded step publishes the new state to the other buffer
         prof_mark(0, 0, st);
         float *rec_p = (tape && pending >= 0) ? tp.rec + (size_t)n_step * REC_WORDS : nullptr;
-        if (grid_search)
-            hipLaunchKernelGGL(knn1_loop_k<true>, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
+        if (grid_search && lb <= 32 * RP_FEW)
+            hipLaunchKernelGGL((knn1_loop_k<true, RP_FEW>), kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
                                (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
-                               w.partials[nxt]);
+                               w.partials[nxt], (const int32_t *)(w.cells + 2 * (size_t)max_ns),
+                               (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns), max_ns, tile_points, src);
+        else if (grid_search)
+            hipLaunchKernelGGL((knn1_loop_k<true, RP_LOADS>), kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
+                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
+                               w.partials[nxt], (const int32_t *)(w.cells + 2 * (size_t)max_ns),
+                               (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns), max_ns, tile_points, src);
         else
-            hipLaunchKernelGGL(knn1_loop_k<false>, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
+            hipLaunchKernelGGL((knn1_loop_k<false, RP_LOADS>), kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
                                (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
-                               w.partials[nxt]);
+                               w.partials[nxt], (const int32_t *)(w.cells + 2 * (size_t)max_ns),
+                               (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns), max_ns, tile_points, src);
         prof_mark(0, 1, st);
         if (pending >= 0) ++n_step;
         cur = nxt;

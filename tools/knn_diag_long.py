@@ -51,7 +51,7 @@ print("prologue (folded step) us per wave p50 %.2f p99 %.2f" % pc((t7 - t6) * ti
 print("prologue end -> search start p50 %.2f" % np.percentile((t0 - t7) * tick, 50))
 w0, ws = a[:, 0, :], a[:, 1:, :]  # wave 0 = the folded step; waves 1.. = the staging path of the grid search
 if (ws[..., 15] > 0).any():
-    rel = lambda slot: (ws[..., slot] - ws[..., 6]) * tick
+    rel = lambda slot: ((ws[..., slot] - ws[..., 6]) * tick)[ws[..., slot] > 0]
     print("staging waves, us after kernel entry (p50): centre + tile displacement known %.2f | bands laid out %.2f | staged to LDS %.2f | barrier passed %.2f ; wave 0 (step) reaches the barrier at %.2f"
           % (np.percentile(rel(13), 50), np.percentile(rel(14), 50), np.percentile(rel(15), 50), np.percentile(rel(7), 50), np.percentile((w0[..., 7] - w0[..., 6]) * tick, 50)))
 print("seed phase us  (per wave)  p50 %.2f p99 %.2f" % pc((t1 - t0) * tick, [50, 99]))
@@ -94,6 +94,24 @@ uniq, counts = np.unique(where, return_counts=True)
 print("distinct CUs used %d ; blocks per CU histogram %s" % (len(uniq), dict(zip(*np.unique(counts, return_counts=True)))))
 per_cu = dict(zip(uniq, counts))
 share = np.array([per_cu[w] for w in where])
+bt = (t3.max(1) - t6.min(1)) * tick
+pro = ((t7 - t6) * tick).max(1)
 for k in sorted(set(share)):
-    print("  blocks on a CU hosting %d block(s): n=%d main loop p50 %.1f us max %.1f us" % (k, (share == k).sum(), np.percentile(ml[share == k], 50), ml[share == k].max()))
+    m = share == k
+    print("  blocks on a CU hosting %d block(s): n=%d main loop p50 %.1f us max %.1f us | prologue p50 %.2f max %.2f | block total p50 %.2f max %.2f" % (
+        k, m.sum(), np.percentile(ml[m], 50), ml[m].max(), np.percentile(pro[m], 50), pro[m].max(), np.percentile(bt[m], 50), bt[m].max()))
+if (ws[..., 15] > 0).any():
+    for k in sorted(set(share)):
+        m = share == k
+        relk = lambda slot: np.percentile(((ws[..., slot] - ws[..., 6]) * tick)[m][ws[..., slot][m] > 0], 50)
+        seed_k, main_k = ((t1 - t0) * tick)[m], ((t2 - t1) * tick)[m]
+        print("  %d block(s) on the CU: staging p50 centre %.2f | bands %.2f | LDS %.2f | barrier %.2f ; wave 0 at the barrier %.2f ; search start %.2f ; seed %.2f main %.2f ; end %.2f" % (
+            k, relk(13), relk(14), relk(15), relk(7), np.percentile(((w0[..., 7] - w0[..., 6]) * tick)[m], 50),
+            np.percentile(((t0 - t6) * tick)[m], 50), np.percentile(seed_k, 50), np.percentile(main_k, 50), np.percentile(((t3 - t6) * tick)[m], 50)))
+if (a[..., 9] > 0).any():
+    for k in sorted(set(share)):
+        m = share == k
+        r = lambda arr: np.percentile(((arr - a[..., 6]) * tick)[m], 50)
+        print("  %d block(s) on the CU: first batch arrived %.2f | rows summed %.2f | wave 0: step done %.2f (us after kernel entry, p50)" % (
+            k, r(a[..., 8]), r(a[..., 9]), np.percentile(((w0[..., 10] - w0[..., 6]) * tick)[m], 50)))
 print("blocks per XCC:", dict(zip(*np.unique(xcc, return_counts=True))))
