@@ -35,9 +35,11 @@
 //    to run, those two gradient arrays are not (sums of a few terms per target in arrival order, ~1e-7 relative).
 #include <stddef.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 #include "gs_common.hpp"
+#include <type_traits>
 #include "gs_project.hpp"
 
 namespace gs {
@@ -248,15 +250,36 @@ __device__ unsigned long long *g_diag = nullptr;
 __device__ __forceinline__ float rlane(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
+// Minimum / maximum over the wave's 64 lanes, uniform result.  Inside each row of 16 lanes by DPP (quad_perm [1,0,3,2],
+// [2,3,0,1], row_half_mirror, row_mirror: eight VALU instructions, no LDS), across the four rows through scalars.  The
+// __shfl_xor butterfly these replace is six DEPENDENT ds_bpermute round trips (~0.3 us per reduction on the planner's path).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <class Op>
+__device__ __forceinline__ int wave_reduce_i(int v, Op op) {
+    v = op(v, dpp_i<0xB1>(v));
+    v = op(v, dpp_i<0x4E>(v));
+    v = op(v, dpp_i<0x141>(v));
+    v = op(v, dpp_i<0x140>(v));
+    return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+              op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+template <class Op>
+__device__ __forceinline__ float wave_reduce_f(float v, Op op) {
+    auto d = [](float x, auto tag) { return __int_as_float(dpp_i<decltype(tag)::value>(__float_as_int(x))); };
+    v = op(v, d(v, std::integral_constant<int, 0xB1>{}));
+    v = op(v, d(v, std::integral_constant<int, 0x4E>{}));
+    v = op(v, d(v, std::integral_constant<int, 0x141>{}));
+    v = op(v, d(v, std::integral_constant<int, 0x140>{}));
+    return op(op(rlane(v, 0), rlane(v, 16)), op(rlane(v, 32), rlane(v, 48)));
+}
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
-    return v;
+    return wave_reduce_f(v, [](float a, float b) { return fminf(a, b); });
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
-    return v;
+    return wave_reduce_f(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // Test the n (<= 64) target points held one per lane in (px,py,pz) with target index pj against the
@@ -351,14 +374,10 @@ struct LaneWin {
     }
 };
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kWave));
-    return v;
+    return wave_reduce_i(v, [](int a, int b) { return min(a, b); });
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
-    return v;
+    return wave_reduce_i(v, [](int a, int b) { return max(a, b); });
 }
 __device__ __forceinline__ int sel4(int k, int a0, int a1, int a2, int a3) { return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3)); }
 
@@ -782,6 +801,22 @@ __device__ __forceinline__ float rp_sum(const float (&a)[RP_LOADS], int nblocks,
     for (int u = 0; u < NL; ++u) v += (k < NACC && b0 + 32 * u < nblocks) ? a[u] : 0.0f;
     return v;
 }
+// knn1_loop_k's form: rows b0, b0 + 32, ... b0 + 32 (NL - 1) exist and hold zeros where no block wrote (partial_rows_alloc,
+// icp_prepare_k), so nothing is clamped or masked -- three instructions per row instead of seven, and each of them is
+// executed by up to sixteen waves on four SIMDs.  Lanes k >= NACC sum words of the neighbouring row: never read.
+template <int NL>
+__device__ __forceinline__ void rp_issue_padded(const float *__restrict__ partials, int b0, float (&a)[RP_LOADS]) {
+    const float *p = partials + b0 * NACC + (threadIdx.x & 31);
+#pragma unroll
+    for (int u = 0; u < RP_LOADS; ++u) a[u] = u < NL ? p[32 * NACC * u] : 0.0f;
+}
+template <int NL>
+__device__ __forceinline__ float rp_sum_padded(const float (&a)[RP_LOADS]) {
+    float v = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) v += a[u];
+    return v;
+}
 __device__ __forceinline__ void rp_finish(float v, float *acc_sm) {
     __shared__ float stage[32][33];
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;  // blockDim.x == 1024 -> g in [0, 32)
@@ -800,10 +835,11 @@ __device__ __forceinline__ void rp_finish(float v, float *acc_sm) {
 // wave leaves its 128 sums in LDS, waits for its OWN LDS writes (the caller's state words among them) and counts itself in;
 // wave 0 waits for the count, then adds the 32 group sums in the same order as rp_finish.  `cnt` must be zero and visible
 // to all waves before the first of them gets here (the caller's raw barrier at kernel start).
-__device__ __forceinline__ void rp_finish_wave0(float v, float *acc_sm, unsigned int *cnt) {
+__device__ __forceinline__ void rp_finish_wave0(float v, int g, float v2, int g2, float *acc_sm, unsigned int *cnt) {
     __shared__ float stage[32][33];
-    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-    stage[k][g] = v;
+    const int k = threadIdx.x & 31;
+    if (g >= 0) stage[k][g] = v;     // (g, g2: the row groups this thread summed, -1 = none -- knn1_loop_k hands the planning
+    if (g2 >= 0) stage[k][g2] = v2;  // waves' groups to two of the waves that only wait)
     if (threadIdx.x >= 64) {
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
@@ -1361,7 +1397,16 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *__rest
     // (consumed only if a step is folded in: then the launch has <= 512 blocks, one round; ten loads cover the 300 rows of a
     // 160 x 120 frame -- every instruction here is executed by sixteen waves on four SIMDs)
     // (NL: the host instantiates the ten-load form for launches of <= 320 blocks)
-    rp_issue<NL>(partials_in, nblocks_in, (int)(threadIdx.x >> 5), rp_a);
+    // GRID: waves 1 and 2 (the planner and the lanes' wave: the critical path of the prologue) sum no rows; their four row
+    // groups are the second duty of waves 14 and 15, which otherwise only wait for the plan.  (Same groups, same order
+    // inside each: the sums do not change.)
+    const int rp_g = (GRID && (wave == 1 || wave == 2)) ? -1 : (int)(threadIdx.x >> 5);
+    const int rp_g2 = (GRID && wave >= 14) ? (int)(threadIdx.x >> 5) - 26 : -1;
+    float rp_b[RP_LOADS];
+#pragma unroll
+    for (int u = 0; u < RP_LOADS; ++u) { rp_a[u] = 0.0f; rp_b[u] = 0.0f; }
+    if (rp_g >= 0) rp_issue_padded<NL>(partials_in, rp_g, rp_a);  // (wave-uniform branches around loads only: nothing is waited for inside)
+    if (rp_g2 >= 0) rp_issue_padded<NL>(partials_in, rp_g2, rp_b);
     static_assert(offsetof(LoopConst, nt) == offsetof(LoopConst, ns) + 4, "ns | nt are read as a pair");
     const int nn = reinterpret_cast<const int *>(&C->ns)[lane & 1];
     int e_h = 0, e_c = -1, e_cam = 0;
@@ -1377,6 +1422,9 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *__rest
         asm volatile("" ::"v"(e_h), "v"(e_c), "v"(e_cam), "v"((unsigned)e_k0), "v"((unsigned)(e_k0 >> 32)),
                      "v"((unsigned)e_k1), "v"((unsigned)(e_k1 >> 32)));
     }
+    if constexpr (GRID)
+        asm volatile("" ::"v"(rp_b[0]), "v"(rp_b[1]), "v"(rp_b[2]), "v"(rp_b[3]), "v"(rp_b[4]), "v"(rp_b[5]), "v"(rp_b[6]), "v"(rp_b[7]), "v"(rp_b[8]),
+                     "v"(rp_b[9]), "v"(rp_b[10]), "v"(rp_b[11]), "v"(rp_b[12]), "v"(rp_b[13]), "v"(rp_b[14]), "v"(rp_b[15]));
     asm volatile("" ::"v"(st_w), "v"(nn), "v"(rp_a[0]), "v"(rp_a[1]), "v"(rp_a[2]), "v"(rp_a[3]), "v"(rp_a[4]), "v"(rp_a[5]), "v"(rp_a[6]),
                  "v"(rp_a[7]), "v"(rp_a[8]), "v"(rp_a[9]), "v"(rp_a[10]), "v"(rp_a[11]), "v"(rp_a[12]), "v"(rp_a[13]), "v"(rp_a[14]),
                  "v"(rp_a[15]));
@@ -1406,9 +1454,14 @@ __global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *__rest
     // Nothing of that depends on the step, so it costs the association no time.
     if (threadIdx.x < kWords) reinterpret_cast<int *>(&st_sm)[threadIdx.x] = st_w;
     if (step_mode >= 0) {
-        const float v = rp_sum<NL>(rp_a, nblocks_in, (int)(threadIdx.x >> 5), 0.0f);
-        if constexpr (GRID) rp_finish_wave0(v, acc_sm, &rp_cnt);  // wave 0 leaves it with acc_sm and every wave's st_sm words visible TO IT
-        else rp_finish(v, acc_sm);                                // ends with a barrier: st_sm and acc_sm are visible
+        if constexpr (GRID) {
+            float v = 0.0f, v2 = 0.0f;
+            if (rp_g >= 0) v = rp_sum_padded<NL>(rp_a);
+            if (rp_g2 >= 0) v2 = rp_sum_padded<NL>(rp_b);
+            rp_finish_wave0(v, rp_g, v2, rp_g2, acc_sm, &rp_cnt);  // wave 0 leaves it with acc_sm and every wave's st_sm words visible TO IT
+        } else {
+            rp_finish(rp_sum_padded<NL>(rp_a), acc_sm);  // ends with a barrier: st_sm and acc_sm are visible
+        }
         GS_STAMP(9);  // (diagnostic build: the rows are summed)
         // (the record takes the state BEFORE the step from the global copy: wave 0 is about to change the LDS one)
         if (blockIdx.x == 0 && rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = st_w;
@@ -1784,8 +1837,13 @@ __global__ void icp_init_state_k(IcpState *S, const float *__restrict__ init_T /
 __global__ __launch_bounds__(SUPER * CHUNK) void icp_prepare_k(IcpState *S, const float *__restrict__ init_T, float damp,
                                                               const float *__restrict__ tgt, const int32_t *__restrict__ d_nt,
                                                               float *__restrict__ boxes, float *__restrict__ sboxes,
-                                                              LoopConst lc, LoopConst *__restrict__ lc_out) {
+                                                              LoopConst lc, LoopConst *__restrict__ lc_out, float *__restrict__ part0,
+                                                              float *__restrict__ part1, int rows_written, int rows_read) {
     static_assert(SUPER * CHUNK == 1024, "one block per super-box");
+    // rows the loop's launches read at kernel start but never write (knn1_loop_k's unmasked row sums): zeros
+    for (int q = rows_written * NACC + blockIdx.x * blockDim.x + threadIdx.x; q < rows_read * NACC; q += gridDim.x * blockDim.x) {
+        part0[q] = 0.0f; part1[q] = 0.0f;
+    }
     __shared__ float wb[16][6];
     if (blockIdx.x == 0 && threadIdx.x < sizeof(LoopConst) / 4) {  // the loop's constants, for its association launches
         int v = reinterpret_cast<const int *>(&lc)[threadIdx.x];
@@ -1942,6 +2000,10 @@ static inline int loop_tile_points() {
 }
 int icp_config_stamp() { return g_grid_mode | (g_tile_points << 4); }  // part of slam.hip's graph-cache key
 static inline int loop_blocks_max(int max_ns) { return cdiv(max_ns, TILE_MIN); }  // workspace: whatever the tile size
+// rows of a partial-sum buffer: the association kernel's prologue reads rows 0 .. 32 RP_LOADS - 1 without testing them against
+// the launch's row count (icp_prepare_k zeroes the rows the loop's launches do not write), four bytes at a time up to twelve
+// bytes past a row's end: one spare row
+static inline int partial_rows_alloc(int max_ns) { return std::max(loop_blocks_max(max_ns), 32 * RP_LOADS) + 1; }
 
 struct IcpWs {
     IcpState *S[2];      // double-buffered across launches (see knn1_loop_k)
@@ -1957,7 +2019,7 @@ static inline size_t icp_ws_layout(int max_ns, int max_nt, void *ws, IcpWs *out)
     const size_t oS = take(sizeof(IcpState)), oS1 = take(sizeof(IcpState));
     const size_t oP0 = take((size_t)max_ns * 12), oP1 = take((size_t)max_ns * 12);
     const size_t oB0 = take((size_t)max_ns * 8), oB1 = take((size_t)max_ns * 8);
-    const size_t oPart = take((size_t)loop_blocks_max(max_ns) * NACC * 4), oPart1 = take((size_t)loop_blocks_max(max_ns) * NACC * 4);
+    const size_t oPart = take((size_t)partial_rows_alloc(max_ns) * NACC * 4), oPart1 = take((size_t)partial_rows_alloc(max_ns) * NACC * 4);
     const size_t oBox = take(boxes_bytes(max_nt)), oSBox = take((size_t)cdiv(max_nt > 0 ? max_nt : 1, 1024) * 6 * 4);
     const size_t oLc = take(sizeof(LoopConst)), oCells = take((size_t)max_ns * 12);  // cells by launch parity (2 planes) | the loop's copy of hints.src_pix
     if (ws && out) {
@@ -2051,7 +2113,8 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
     LoopConst lc{src, tgt, nrm, w.boxes, w.sboxes, d_ns, d_nt, trace, out_T, hints, gp, thresh, 0, 0, cert_off, tile_points,
                  grid_search ? 1 : 0, CamK{}, 0, w.cells, max_ns};
     hipLaunchKernelGGL(icp_prepare_k, dim3(cdiv(max_nt, SUPER * CHUNK)), dim3(SUPER * CHUNK), 0, st, w.S[0], init_T, damp,
-                       hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc);
+                       hints.scan_points ? hints.scan_points : tgt, d_nt, w.boxes, w.sboxes, lc, w.lc, w.partials[0], w.partials[1], lb,
+                       std::max(lb, 32 * RP_LOADS));
     GS_LAUNCH_CHECK(name);
     // The loop as a sequence  A S A S ... A S  (A = association + linearise launch, S = O(1) step on A's sums).
     // Every S but the last runs in the prologue of the A that follows it; state and partial sums alternate
