@@ -1349,12 +1349,15 @@ __device__ __forceinline__ float cam_bound2(const CamK &k, const f3 s, const int
 }
 
 template <bool GRID, int NL>
-__global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *__restrict__ C, const IcpState *__restrict__ S_in, IcpState *__restrict__ S_out,
-                                                         const float *__restrict__ partials_in, int nblocks_in, int step_mode,
-                                                         int look_slot, float *__restrict__ rec, int phase /* first | launch parity << 1 */,
-                                                         int out_slot, LoopBufs B, float *__restrict__ partials /* gridDim.x x NACC */,
-                                                         const int32_t *__restrict__ pix_ws, const int32_t *__restrict__ cells_in, int cap,
-                                                         int tile_points, const float *__restrict__ user_src) {
+// (argument order: what the first batch of requests needs comes first -- the leading sixteen dwords of the kernel arguments
+// can be preloaded into SGPRs with the dispatch, -amdgpu-kernarg-preload-count in the Makefile)
+__global__ __launch_bounds__(KNN_BT, 8) void knn1_loop_k(const LoopConst *__restrict__ C, const IcpState *__restrict__ S_in,
+                                                         const float *__restrict__ partials_in, const int32_t *__restrict__ pix_ws,
+                                                         const int32_t *__restrict__ cells_in, int cap, int tile_points,
+                                                         int phase /* first | launch parity << 1 */, int step_mode, int look_slot,
+                                                         int nblocks_in, IcpState *__restrict__ S_out, float *__restrict__ rec, int out_slot,
+                                                         LoopBufs B, float *__restrict__ partials /* gridDim.x x NACC */,
+                                                         const float *__restrict__ user_src) {
     const int first = phase & 1, par = phase >> 1;
     __shared__ KnnShared sh;
     __shared__ IcpState st_sm;
@@ -2138,21 +2141,15 @@ static int icp_run(bool grad, const float *src, const int32_t *d_ns, int max_ns,
         const int nxt = pending >= 0 ? 1 - cur : cur;  // a folded step publishes the new state to the other buffer
         prof_mark(0, 0, st);
         float *rec_p = (tape && pending >= 0) ? tp.rec + (size_t)n_step * REC_WORDS : nullptr;
-        if (grid_search && lb <= 32 * RP_FEW)
-            hipLaunchKernelGGL((knn1_loop_k<true, RP_FEW>), kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
-                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
-                               w.partials[nxt], (const int32_t *)(w.cells + 2 * (size_t)max_ns),
-                               (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns), max_ns, tile_points, src);
-        else if (grid_search)
-            hipLaunchKernelGGL((knn1_loop_k<true, RP_LOADS>), kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
-                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
-                               w.partials[nxt], (const int32_t *)(w.cells + 2 * (size_t)max_ns),
-                               (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns), max_ns, tile_points, src);
-        else
-            hipLaunchKernelGGL((knn1_loop_k<false, RP_LOADS>), kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], w.S[nxt],
-                               (const float *)w.partials[cur], lb, pending, pending_slot, rec_p, first | ((n_assoc & 1) << 1), tape ? n_assoc : -1, w.B,
-                               w.partials[nxt], (const int32_t *)(w.cells + 2 * (size_t)max_ns),
-                               (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns), max_ns, tile_points, src);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, kgrid, dim3(KNN_BT), 0, st, (const LoopConst *)w.lc, (const IcpState *)w.S[cur], (const float *)w.partials[cur],
+                               (const int32_t *)(w.cells + 2 * (size_t)max_ns), (const int32_t *)(w.cells + (size_t)(1 - (n_assoc & 1)) * max_ns),
+                               max_ns, tile_points, first | ((n_assoc & 1) << 1), pending, pending_slot, lb, w.S[nxt], rec_p,
+                               tape ? n_assoc : -1, w.B, w.partials[nxt], src);
+        };
+        if (grid_search && lb <= 32 * RP_FEW) launch(knn1_loop_k<true, RP_FEW>);
+        else if (grid_search) launch(knn1_loop_k<true, RP_LOADS>);
+        else launch(knn1_loop_k<false, RP_LOADS>);
         prof_mark(0, 1, st);
         if (pending >= 0) ++n_step;
         cur = nxt;

@@ -10,7 +10,7 @@ k.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in k])
 gap = np.array([(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(k[:-1], k[1:])])
 n = len(d) // per * per
-print("launches", len(d), "mean us %.2f" % d.mean(), "grid variant:", sum("ILb1" in r["Kernel_Name"] or "<true>" in r["Kernel_Name"] for r in k))
+print("launches", len(d), "mean us %.2f" % d.mean(), "grid variant:", sum("ILb1" in r["Kernel_Name"] or "<true" in r["Kernel_Name"] for r in k))
 m = d[:n].reshape(-1, per)
 print("by position in the loop (mean us over %d loops):" % m.shape[0], " ".join("%.1f" % x for x in m.mean(0)))
 print("last loop:", " ".join("%.1f" % x for x in m[-1]))
