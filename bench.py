@@ -560,7 +560,7 @@ def main():
                        "timing": "median of {} timed regions of {} steps each".format(len(dts), args.steps)},
             "roofline_timed_region": {
                 "kernel": "knn1_loop_k<true> (X+K+J fused: the previous iteration's O(1) step -- reduce, LM decision, 6x6 solve, exp -- "
-                          "on wave 0 while the other waves stage the windows; then rigid transform, exact 1-NN association by grid "
+                          "on wave 0 while one wave plans the tile's windows, one prepares the lanes' rows and seeds and thirteen stage the targets; then rigid transform, exact 1-NN association by grid "
                           "search with a geometric proof per point (exact chunk-box search for the points it fails for), "
                           "Jacobian rows and 29-term reduce of its 64-point tile)",
                 "launches": n_knn, "avg_launch_ms": round(avg_knn_ms, 5),
