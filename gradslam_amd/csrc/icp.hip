@@ -2391,7 +2391,7 @@ __device__ double solve_bwd(const float *H, float damp, const float *xi, const d
 enum BwdFold { FOLD_G1 = 1, FOLD_G2 = 2, FOLD_LM = 3 };
 
 // S for one LM iteration (record = the STEP_LM record of that iteration)
-__device__ void small_lm(BwdState *Sb, const float *__restrict__ rec, const float *sums, int iter) {
+__device__ void small_lm(BwdState *Sb, const float *rec, const float *__restrict__ rec_global, const float *sums, int iter) {
     const IcpState *S = rec_state(rec);
     if (rec[REC_ACCEPT] == 0.0f) { Sb->active = 0; return; }
     double gdT[12], gxi[6];
@@ -2407,7 +2407,7 @@ __device__ void small_lm(BwdState *Sb, const float *__restrict__ rec, const floa
     // the cloud of this iteration was made by the closest earlier accepted iteration (from ITS cloud)
     int prev = -1;
     for (int j = iter - 1; j >= 0 && prev < 0; --j) {
-        const float *rj = rec - (size_t)(iter - j) * REC_WORDS;
+        const float *rj = rec_global - (size_t)(iter - j) * REC_WORDS;  // (earlier records: not in the LDS copy)
         if (rj[REC_ACCEPT] != 0.0f) prev = rec_state(rj)->p_cur;
     }
     Sb->prev_slot = prev;
@@ -2415,7 +2415,7 @@ __device__ void small_lm(BwdState *Sb, const float *__restrict__ rec, const floa
 }
 
 // S1 for one gradLM iteration (record = its STEP_GRAD_B record; the next record's head = the state after)
-__device__ void small_g1(BwdState *Sb, const float *__restrict__ rec, const float *sums, GradParams gp, int prev_slot) {
+__device__ void small_g1(BwdState *Sb, const float *rec, const float *sums, GradParams gp, int prev_slot) {
     const IcpState *S = rec_state(rec), *Sn = rec_state(rec + REC_WORDS);
     const float err = S->cur[42], new_err = rec[REC_LIN + 42];
     const float raw = new_err - err;
@@ -2448,7 +2448,7 @@ __device__ void small_g1(BwdState *Sb, const float *__restrict__ rec, const floa
 }
 
 // S2: look-ahead step dT1 = exp(xi) -> xi ; then the solve
-__device__ void small_g2(BwdState *Sb, const float *__restrict__ rec, const float *sums) {
+__device__ void small_g2(BwdState *Sb, const float *rec, const float *sums) {
     const IcpState *S = rec_state(rec);
     double gdT1[12], gxi[6];
     for (int k = 0; k < 12; ++k) gdT1[k] = (double)sums[k];
@@ -2459,22 +2459,54 @@ __device__ void small_g2(BwdState *Sb, const float *__restrict__ rec, const floa
     Sb->G[42] = Sb->g_err; Sb->G[43] = 0.0f;
 }
 
-// prologue of the wide kernels: the folded small step on an LDS copy of the state; ends with a barrier
+// prologue of the wide kernels: the folded small step on an LDS copy of the state; ends with a barrier.
+// Everything the step reads -- the state, its tape record with the head of the next one, the partial rows -- is requested in
+// ONE batch at kernel start and handed over through LDS: the step runs on one lane, and every global word it used to
+// fetch for itself (the record's state, sums, flags: a dozen dependent round trips) is an LDS read now; the rows' loads
+// used to follow each other through a four-deep loop (same order of summation as reduce12: the sums do not change).
 __device__ __forceinline__ void bwd_fold(BwdState &sb, const BwdState *__restrict__ Sb_in, BwdState *__restrict__ Sb_out, int fold,
                                          const float *__restrict__ rec, const float *__restrict__ partials_in, int nblocks,
                                          GradParams gp, int arg) {
     __shared__ float sums[12];
-    constexpr int kWords = sizeof(BwdState) / 4;
+    __shared__ float rec_sm[2 * REC_WORDS];
+    __shared__ float stage[12][17];
+    constexpr int kWords = sizeof(BwdState) / 4, RU = 8;
     static_assert(kWords <= BWD_T, "state copied by one pass of the block");
-    if (threadIdx.x < kWords) reinterpret_cast<int *>(&sb)[threadIdx.x] = reinterpret_cast<const int *>(Sb_in)[threadIdx.x];
-    reduce12(partials_in, nblocks, sums);  // ends with a barrier: sb and sums are visible
-    if (threadIdx.x == 0) {
-        if (fold == FOLD_G1) small_g1(&sb, rec, sums, gp, arg);
-        else if (fold == FOLD_G2) small_g2(&sb, rec, sums);
-        else small_lm(&sb, rec, sums, arg);
+    static_assert(BWD_T < 2 * REC_WORDS && 2 * REC_WORDS <= 2 * BWD_T, "record pair copied by two loads per thread");
+    const int t = threadIdx.x, k = t & 15, g = t >> 4, kc = min(k, 11), last = max(nblocks - 1, 0);
+    const int sw = reinterpret_cast<const int *>(Sb_in)[min(t, kWords - 1)];
+    const float r0 = rec[t], r1 = rec[BWD_T + min(t, 2 * REC_WORDS - BWD_T - 1)];
+    float a[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) a[u] = partials_in[min(g + 16 * u, last) * 12 + kc];
+    if (t < kWords) reinterpret_cast<int *>(&sb)[t] = sw;
+    rec_sm[t] = r0;
+    if (t < 2 * REC_WORDS - BWD_T) rec_sm[BWD_T + t] = r1;
+    float v = 0.0f;
+#pragma unroll
+    for (int u = 0; u < RU; ++u) v += (g + 16 * u < nblocks) ? a[u] : 0.0f;
+    for (int b0 = g + 16 * RU; b0 < nblocks; b0 += 16 * RU) {  // (more than 128 rows: further rounds)
+#pragma unroll
+        for (int u = 0; u < RU; ++u) a[u] = partials_in[min(b0 + 16 * u, last) * 12 + kc];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) v += (b0 + 16 * u < nblocks) ? a[u] : 0.0f;
+    }
+    if (k < 12) stage[k][g] = v;
+    __syncthreads();
+    if (t < 12) {
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q += stage[t][j];
+        sums[t] = q;
+    }
+    __syncthreads();  // sb, rec_sm and sums are visible
+    if (t == 0) {
+        if (fold == FOLD_G1) small_g1(&sb, rec_sm, sums, gp, arg);
+        else if (fold == FOLD_G2) small_g2(&sb, rec_sm, sums);
+        else small_lm(&sb, rec_sm, rec, sums, arg);
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < kWords) reinterpret_cast<int *>(Sb_out)[threadIdx.x] = reinterpret_cast<const int *>(&sb)[threadIdx.x];
+    if (blockIdx.x == 0 && t < kWords) reinterpret_cast<int *>(Sb_out)[t] = reinterpret_cast<const int *>(&sb)[t];
 }
 
 // B (gradLM), with S1 folded in: adjoint of new_err = e(look, NN(look)); gP_i <- R2^T gP_i + R1^T glook_i ; sums glook (x) s
