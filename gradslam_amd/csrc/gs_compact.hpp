@@ -22,7 +22,8 @@ template <class W, class = void>
 struct writer_has_skip : std::false_type {};
 template <class W>
 struct writer_has_skip<W, std::void_t<decltype(&W::skip)>> : std::true_type {};
-// a Pred may provide block_init(pass), run once by every block of both passes (pass 0 = count, 1 = write) before
+// a Pred may provide block_init(pass, bid, nb), run once by every block of both passes (pass 0 = count, 1 = write; bid / nb =
+// the block's index and the number of blocks of THIS compaction, which need not be the launch's grid) before
 // the first item and followed by a barrier: per-block constants go to LDS there, and small side jobs ride along,
 // instead of costing a preparation launch
 template <class P, class = void>
@@ -54,28 +55,30 @@ static inline size_t compact_ws_bytes(int64_t n) { return align_up(2 * sizeof(in
 // `flags` (optional, one byte per thread = its kCI verdicts): the write pass then reads the verdicts instead of evaluating the
 // predicate again -- for predicates that cost more to evaluate than a byte costs to move (the projection: two IEEE
 // divisions per point; the write pass of a 1.7 M-point map took 18 us re-projecting, 12 B per point re-read).
+// (bodies as device functions of a VIRTUAL block index / block count: compact_count2_k / compact_write2_k below run two
+// independent compactions in one launch each, the second behind the first in the grid)
 template <class Pred>
-__global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts,
-                                                       unsigned char *__restrict__ flags = nullptr) {
+__device__ __forceinline__ void compact_count_body(int64_t n, const Pred &pred, int *__restrict__ block_counts,
+                                                   unsigned char *__restrict__ flags, int bid, int nb) {
     __shared__ int sm[kCT / 64];
-    const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
+    const int64_t base = (int64_t)bid * kCB + (int64_t)threadIdx.x * kCI;
     int c = 0;
     if constexpr (pred_has_fetch<Pred>::value) {
         typename Pred::Item it[kCI];  // (fetched before the block's preparation: its loads overlap these)
 #pragma unroll
         for (int k = 0; k < kCI; ++k) it[k] = pred.fetch(base + k < n ? base + k : 0);
         if constexpr (pred_has_block_init<Pred>::value) {
-            pred.block_init(0);
+            pred.block_init(0, bid, nb);
             __syncthreads();
         }
         int bits = 0;
 #pragma unroll
         for (int k = 0; k < kCI; ++k)
             if (base + k < n && pred.test(it[k], base + k)) { ++c; bits |= 1 << k; }
-        if (flags) flags[(int64_t)blockIdx.x * kCT + threadIdx.x] = (unsigned char)bits;
+        if (flags) flags[(int64_t)bid * kCT + threadIdx.x] = (unsigned char)bits;
     } else {
         if constexpr (pred_has_block_init<Pred>::value) {
-            pred.block_init(0);
+            pred.block_init(0, bid, nb);
             __syncthreads();
         }
         int bits = 0;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int
             const int64_t i = base + k;
             if (i < n && pred(i)) { ++c; bits |= 1 << k; }
         }
-        if (flags) flags[(int64_t)blockIdx.x * kCT + threadIdx.x] = (unsigned char)bits;
+        if (flags) flags[(int64_t)bid * kCT + threadIdx.x] = (unsigned char)bits;
     }
     c = wave_sum_i(c);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
@@ -92,8 +95,13 @@ __global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int
     if (threadIdx.x == 0) {
         int s = 0;
         for (int w = 0; w < kCT / 64; ++w) s += sm[w];
-        block_counts[blockIdx.x] = s;
+        block_counts[bid] = s;
     }
+}
+template <class Pred>
+__global__ __launch_bounds__(kCT) void compact_count_k(int64_t n, Pred pred, int *__restrict__ block_counts,
+                                                       unsigned char *__restrict__ flags = nullptr) {
+    compact_count_body(n, pred, block_counts, flags, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // single block; out_total[0] = sum, optionally added to *accum_base first (for segmented use)
@@ -119,14 +127,14 @@ static __global__ __launch_bounds__(1024) void compact_scan_k(const int *__restr
 constexpr int kSelfScanBlocks = 1024;
 
 // sum of counts[0 .. blockIdx.x) by the whole block; the last block also publishes the grand total
-__device__ __forceinline__ int self_scan_offset(const int *__restrict__ block_counts, int *__restrict__ out_total) {
+__device__ __forceinline__ int self_scan_offset(const int *__restrict__ block_counts, int *__restrict__ out_total, int bid, int nb) {
     __shared__ int red[kCT / 64];
     __shared__ int result;
     int mine = 0, all = 0;
-    const bool last = blockIdx.x == gridDim.x - 1;
-    for (int j = threadIdx.x; j < (int)gridDim.x; j += kCT) {
-        const int c = (j < (int)blockIdx.x || last) ? block_counts[j] : 0;
-        if (j < (int)blockIdx.x) mine += c;
+    const bool last = bid == nb - 1;
+    for (int j = threadIdx.x; j < nb; j += kCT) {
+        const int c = (j < bid || last) ? block_counts[j] : 0;
+        if (j < bid) mine += c;
         all += c;
     }
     mine = wave_sum_i(mine);
@@ -153,19 +161,18 @@ __device__ __forceinline__ int self_scan_offset(const int *__restrict__ block_co
     return off;
 }
 
-template <class Pred, class Writer, bool SelfScan = false>
-__global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Writer writer,
-                                                       const int *__restrict__ block_offsets /* SelfScan: block COUNTS */,
-                                                       int *__restrict__ out_total = nullptr,
-                                                       const unsigned char *__restrict__ flags = nullptr) {
+template <class Pred, class Writer, bool SelfScan>
+__device__ __forceinline__ void compact_write_body(int64_t n, const Pred &pred, const Writer &writer,
+                                                   const int *__restrict__ block_offsets /* SelfScan: block COUNTS */,
+                                                   int *__restrict__ out_total, const unsigned char *__restrict__ flags, int bid, int nb) {
     __shared__ int sm[kCT / 64 + 1];
-    const int my_bits = flags ? flags[(int64_t)blockIdx.x * kCT + threadIdx.x] : 0;  // (requested before everything else)
+    const int my_bits = flags ? flags[(int64_t)bid * kCT + threadIdx.x] : 0;  // (requested before everything else)
     if constexpr (pred_has_block_init<Pred>::value) {
-        pred.block_init(1);
+        pred.block_init(1, bid, nb);
         __syncthreads();
     }
-    const int block_base = SelfScan ? self_scan_offset(block_offsets, out_total) : block_offsets[blockIdx.x];
-    const int64_t base = (int64_t)blockIdx.x * kCB + (int64_t)threadIdx.x * kCI;
+    const int block_base = SelfScan ? self_scan_offset(block_offsets, out_total, bid, nb) : block_offsets[bid];
+    const int64_t base = (int64_t)bid * kCB + (int64_t)threadIdx.x * kCI;
     bool f[kCI];
     int c = 0;
     if (flags) {  // the count pass's verdicts: no predicate, no fetch; the writer loads what it needs for the rows it writes
@@ -225,6 +232,30 @@ __global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Wri
         }
     }
 }
+template <class Pred, class Writer, bool SelfScan = false>
+__global__ __launch_bounds__(kCT) void compact_write_k(int64_t n, Pred pred, Writer writer,
+                                                       const int *__restrict__ block_offsets /* SelfScan: block COUNTS */,
+                                                       int *__restrict__ out_total = nullptr,
+                                                       const unsigned char *__restrict__ flags = nullptr) {
+    compact_write_body<Pred, Writer, SelfScan>(n, pred, writer, block_offsets, out_total, flags, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two independent compactions in ONE launch per pass: blocks [0, nbA) run A, blocks [nbA, nbA + nbB) run B.  For a small job
+// whose inputs are ready at the same time as a large one's (the ds-grid source cloud of a frame next to the projection of
+// the map): its two launches (~5 us each, latency) disappear into the large job's.
+template <class PA, class PB>
+__global__ __launch_bounds__(kCT) void compact_count2_k(int64_t nA, PA pa, int *__restrict__ countsA, unsigned char *__restrict__ flagsA, int nbA,
+                                                        int64_t nB, PB pb, int *__restrict__ countsB, int nbB) {
+    if ((int)blockIdx.x < nbA) compact_count_body(nA, pa, countsA, flagsA, (int)blockIdx.x, nbA);
+    else compact_count_body(nB, pb, countsB, (unsigned char *)nullptr, (int)blockIdx.x - nbA, nbB);
+}
+template <class PA, class WA, bool SelfScanA, class PB, class WB>
+__global__ __launch_bounds__(kCT) void compact_write2_k(int64_t nA, PA pa, WA wa, const int *__restrict__ offsetsA, int *__restrict__ totalA,
+                                                        const unsigned char *__restrict__ flagsA, int nbA, int64_t nB, PB pb, WB wb,
+                                                        const int *__restrict__ countsB, int *__restrict__ totalB, int nbB) {
+    if ((int)blockIdx.x < nbA) compact_write_body<PA, WA, SelfScanA>(nA, pa, wa, offsetsA, totalA, flagsA, (int)blockIdx.x, nbA);
+    else compact_write_body<PB, WB, true>(nB, pb, wb, countsB, totalB, (const unsigned char *)nullptr, (int)blockIdx.x - nbA, nbB);
+}
 
 // Enqueue the launches.  ws must hold compact_ws_bytes(n).
 // (A one-block, one-launch variant for small inputs was measured and rejected: 19 200 candidates on a single CU
@@ -249,6 +280,32 @@ static inline int compact_launch(int64_t n, Pred pred, Writer writer, int *d_out
     GS_LAUNCH_CHECK(name);
     hipLaunchKernelGGL((compact_write_k<Pred, Writer, false>), dim3(nb), dim3(kCT), 0, st, n, pred, writer, offsets,
                        (int *)nullptr, (const unsigned char *)flags);
+    GS_LAUNCH_CHECK(name);
+    return GS_OK;
+}
+
+// compact_launch for job A (with optional verdict bytes) and a small job B (at most kSelfScanBlocks blocks) side by side;
+// wsA / wsB must hold compact_ws_bytes(nA) / compact_ws_bytes(nB)
+template <class PA, class WA, class PB, class WB>
+static inline int compact_launch2(int64_t nA, PA pa, WA wa, int *d_countA, void *wsA, unsigned char *flagsA, int64_t nB, PB pb, WB wb,
+                                  int *d_countB, void *wsB, hipStream_t st, const char *name) {
+    const int nbA = compact_blocks(nA), nbB = compact_blocks(nB);
+    if (nbB > kSelfScanBlocks) {
+        set_error("%s: second compaction too large for the fused form", name);
+        return GS_ERR_INVALID_ARG;
+    }
+    int *countsA = (int *)wsA, *offsetsA = countsA + nbA, *countsB = (int *)wsB;
+    hipLaunchKernelGGL((compact_count2_k<PA, PB>), dim3(nbA + nbB), dim3(kCT), 0, st, nA, pa, countsA, flagsA, nbA, nB, pb, countsB, nbB);
+    GS_LAUNCH_CHECK(name);
+    if (nbA <= kSelfScanBlocks) {
+        hipLaunchKernelGGL((compact_write2_k<PA, WA, true, PB, WB>), dim3(nbA + nbB), dim3(kCT), 0, st, nA, pa, wa, (const int *)countsA, d_countA,
+                           (const unsigned char *)flagsA, nbA, nB, pb, wb, (const int *)countsB, d_countB, nbB);
+    } else {
+        hipLaunchKernelGGL(compact_scan_k, dim3(1), dim3(1024), 0, st, countsA, nbA, offsetsA, d_countA);
+        GS_LAUNCH_CHECK(name);
+        hipLaunchKernelGGL((compact_write2_k<PA, WA, false, PB, WB>), dim3(nbA + nbB), dim3(kCT), 0, st, nA, pa, wa, (const int *)offsetsA,
+                           (int *)nullptr, (const unsigned char *)flagsA, nbA, nB, pb, wb, (const int *)countsB, d_countB, nbB);
+    }
     GS_LAUNCH_CHECK(name);
     return GS_OK;
 }

@@ -54,4 +54,38 @@ __device__ __forceinline__ bool project_point(const Cam &c, f3 p, int H, int W, 
     return in;
 }
 
+
+// ------------------------------------------------------------------ the ds-grid source cloud of a frame (gs_downsample_frame)
+// reference structures/structutils.py downsample_rgbdimages: every ds-th pixel of every ds-th row with valid depth
+struct DsPred {
+    const float *depth;  // (H,W) of one batch element
+    int W, Wd, ds;
+    __device__ bool operator()(int64_t i) const {
+        const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
+        return depth[(int64_t)(r * ds) * W + c * ds] > 0.0f;
+    }
+};
+struct DsWriter {
+    const float *gv, *gn, *rgb;
+    float *op, *on, *oc;
+    int32_t *opix;
+    int W, Wd, ds;
+    __device__ void operator()(int64_t i, int64_t pos) const {
+        const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
+        const int64_t pix = (int64_t)(r * ds) * W + c * ds;
+        if (opix) opix[pos] = (int32_t)i;  // ds-grid pixel id r * Wd + c
+        if (op) st3(op, pos, ld3(gv, pix));
+        if (on) st3(on, pos, ld3(gn, pix));
+        if (oc) st3(oc, pos, ld3(rgb, pix));
+    }
+};
+
+// one sequence's job for project_target1 (project.hip), which runs it on the launches of the map's projection
+struct DsJob {
+    const float *depth, *gvertex;  // (H, W), (H, W, 3)
+    float *out_points;             // (cap, 3)
+    int32_t *out_pix;              // (cap)
+    int32_t *count;                // device count of selected pixels
+};
+
 }  // namespace gs

@@ -8,6 +8,7 @@
 
 #include "gs_common.hpp"
 #include "gs_compact.hpp"
+#include "gs_project.hpp"
 
 namespace gs {
 
@@ -372,28 +373,7 @@ __global__ void alpha_bwd_k(const float *__restrict__ pts, int64_t n, float den,
 }
 
 // ------------------------------------------------------------------ frame downsample (D)
-struct DsPred {
-    const float *depth;  // (H,W) of one batch element
-    int W, Wd, ds;
-    __device__ bool operator()(int64_t i) const {
-        const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
-        return depth[(int64_t)(r * ds) * W + c * ds] > 0.0f;
-    }
-};
-struct DsWriter {
-    const float *gv, *gn, *rgb;
-    float *op, *on, *oc;
-    int32_t *opix;
-    int W, Wd, ds;
-    __device__ void operator()(int64_t i, int64_t pos) const {
-        const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
-        const int64_t pix = (int64_t)(r * ds) * W + c * ds;
-        if (opix) opix[pos] = (int32_t)i;  // ds-grid pixel id r * Wd + c
-        if (op) st3(op, pos, ld3(gv, pix));
-        if (on) st3(on, pos, ld3(gn, pix));
-        if (oc) st3(oc, pos, ld3(rgb, pix));
-    }
-};
+// (DsPred / DsWriter: gs_project.hpp -- project.hip runs them next to the map's projection in gs_slam_localize)
 
 // ------------------------------------------------------------------ generic row compaction
 struct MaskPred {

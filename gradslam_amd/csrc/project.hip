@@ -74,7 +74,7 @@ struct ActivePredL {
     const float *poses, *Ks;
     int B, Nmax, H, W, ds;
     float umax, vmax;
-    __device__ void block_init(int /*pass*/) const {
+    __device__ void block_init(int /*pass*/, int /*bid*/, int /*nb*/) const {
         for (int b = threadIdx.x; b < B; b += blockDim.x) cam_cache()[b] = make_cam(poses + 16 * b, Ks + 16 * b);
     }
     struct Item { f3 p; };
@@ -115,10 +115,10 @@ struct ActivePredH {
     float umax, vmax;
     int *cnt, *fill;  // (npix) each
     int npix;
-    __device__ void block_init(int pass) const {
+    __device__ void block_init(int pass, int bid, int nb) const {
         if (threadIdx.x == 0) cam_cache()[0] = make_cam(poses, Ks);
         if (pass == 0)
-            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) { cnt[i] = 0; fill[i] = 0; }
+            for (int i = bid * blockDim.x + threadIdx.x; i < npix; i += nb * blockDim.x) { cnt[i] = 0; fill[i] = 0; }
     }
     struct Item { f3 p; };
     __device__ Item fetch(int64_t i) const { return Item{ld3(points, i)}; }
@@ -356,12 +356,14 @@ namespace gs {
 // gs_project_active (ds-grid) + gs_build_icp_target for one sequence in 4 launches instead of 6 (see ActivePredH)
 size_t project_target1_ws_bytes(int H, int W, int ds, int Nmax) {
     const size_t npix = (size_t)cdiv(H, ds) * cdiv(W, ds);
-    return compact_ws_bytes(Nmax) + 2 * align_up(npix * 4, 256) + compact_flags_bytes(Nmax);
+    return compact_ws_bytes(Nmax) + 2 * align_up(npix * 4, 256) + compact_flags_bytes(Nmax) + compact_ws_bytes((int64_t)npix);
 }
+// `frame` (optional): the ds-grid source cloud of the live frame (gs_downsample_frame for one sequence) rides on the same two
+// launches -- its inputs (the maps kernel's output) are ready when the projection's are
 int project_target1(const float *points, const int32_t *counts, int Nmax, const float *poses, const float *intrinsics, int H,
                     int W, int ds, const float *map_normals, int cap, int64_t *rows, int32_t *nrows, float *tgt, float *tnrm,
                     int32_t *nt, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, int32_t *tgt_pix,
-                    void *ws, size_t ws_bytes, hipStream_t st) {
+                    void *ws, size_t ws_bytes, hipStream_t st, const DsJob *frame) {
     const char *name = "gs_slam_localize/target";
     if (!ws || ws_bytes < project_target1_ws_bytes(H, W, ds, Nmax)) {
         set_error("%s: workspace too small", name);
@@ -375,7 +377,16 @@ int project_target1(const float *points, const int32_t *counts, int Nmax, const 
     const float umax = (float)((double)W - 0.999), vmax = (float)((double)H - 0.999);
     ActivePredH pred{points, counts, poses, intrinsics, Nmax, H, W, ds, umax, vmax, cnt, fill, npix};
     ActiveWriterH wr{points, rows, H, W, ds, Wd, umax, vmax, cnt};
-    const int rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name, flags);
+    int rc;
+    if (frame) {
+        const int Hd = cdiv(H, ds);
+        DsPred dp{frame->depth, W, Wd, ds};
+        DsWriter dw{frame->gvertex, nullptr, nullptr, frame->out_points, nullptr, nullptr, frame->out_pix, W, Wd, ds};
+        void *dws = (char *)flags + compact_flags_bytes(Nmax);  // (the frame's block counts: behind everything the projection uses)
+        rc = compact_launch2((int64_t)Nmax, pred, wr, nrows, cws, flags, (int64_t)Hd * Wd, dp, dw, frame->count, dws, st, name);
+    } else {
+        rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name, flags);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(pix_scan_k, dim3(1), dim3(1024), 0, st, cnt, npix, pix_start);
     hipLaunchKernelGGL(tgt_scatter_gather1_k, dim3(min(cdiv(Nmax, 256), 1024)), dim3(256), 0, st, rows, nrows, points, map_normals, cap,

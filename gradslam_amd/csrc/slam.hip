@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "gs_common.hpp"
+#include "gs_project.hpp"
 
 namespace gs {
 
@@ -89,7 +90,7 @@ size_t project_target1_ws_bytes(int H, int W, int ds, int Nmax);
 int project_target1(const float *points, const int32_t *counts, int Nmax, const float *poses, const float *intrinsics, int H,
                     int W, int ds, const float *map_normals, int cap, int64_t *rows, int32_t *nrows, float *tgt, float *tnrm,
                     int32_t *nt, float *scan_points, int32_t *scan_orig, int32_t *pix_start, int32_t *tgt_index, int32_t *tgt_pix,
-                    void *ws, size_t ws_bytes, hipStream_t st);
+                    void *ws, size_t ws_bytes, hipStream_t st, const DsJob *frame);
 
 struct LocWs {
     float *src;        // (B, capS, 3)
@@ -352,15 +353,17 @@ int gs_slam_localize(const float *depth, const float *intrinsics, const float *p
     // (the maps kernel also leaves the bucketing camera -- previous pose and intrinsics -- in the workspace: the loops read it
     // from there, an address a captured graph may keep, never from the caller's tensors)
     if ((rc = vertex_normal_maps_cam(depth, intrinsics, prev_poses, B, H, W, vertex, normal, gvertex, gnormal, w.cam, st))) return rc;
-    if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.src_pix, w.ns,
-                                  w.sub, w.sub_bytes, stream))) return rc;
     // map points that land on the ds-grid of the previous frame: the ICP target
     // reference-order target (points, normals, counts) + the same points in pixel order and the first scan
-    // slot of every ds-grid pixel (search hints only); one sequence takes the 4-launch fused form
+    // slot of every ds-grid pixel (search hints only); one sequence takes the 4-launch fused form, and the frame's ds-grid
+    // source cloud rides on its first two launches (two launches of ~5 us less on the step's chain)
     if (B == 1) {
+        const DsJob frame{depth, gvertex, w.src, w.src_pix, w.ns};
         if ((rc = project_target1(map_points, map_counts, Nmax, prev_poses, intrinsics, H, W, ds, map_normals, capT, w.rows, w.nrows,
-                                  w.tgt, w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, nullptr, w.sub, w.sub_bytes, st))) return rc;
+                                  w.tgt, w.tnrm, w.nt, w.scan, w.scan_orig, w.pix_start, nullptr, nullptr, w.sub, w.sub_bytes, st, &frame))) return rc;
     } else {
+        if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, w.src, nullptr, nullptr, w.src_pix, w.ns,
+                                      w.sub, w.sub_bytes, stream))) return rc;
         if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
                                     w.sub_bytes, stream))) return rc;
         if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
@@ -637,13 +640,14 @@ int gs_slam_localize_taped(const float *depth, const float *gvertex, const float
     loc_tape_layout(B, H, W, ds, Nmax, numiters, use_grad_lm, tape, &tp);
     const int capS = cdiv(H, ds) * cdiv(W, ds), capT = target_cap(Nmax);
     int rc;
-    if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, tp.src, nullptr, nullptr, tp.src_pix, tp.ns,
-                                  w.sub, w.sub_bytes, stream))) return rc;
     if (B == 1) {
+        const DsJob frame{depth, gvertex, tp.src, tp.src_pix, tp.ns};
         if ((rc = project_target1(map_points, map_counts, Nmax, prev_poses, intrinsics, H, W, ds, map_normals, capT, w.rows, w.nrows,
                                   w.tgt, w.tnrm, tp.nt, w.scan, w.scan_orig, w.pix_start, tp.tgt_index, nullptr, w.sub, w.sub_bytes,
-                                  (hipStream_t)stream))) return rc;
+                                  (hipStream_t)stream, &frame))) return rc;
     } else {
+        if ((rc = gs_downsample_frame(depth, gvertex, nullptr, nullptr, B, H, W, ds, capS, tp.src, nullptr, nullptr, tp.src_pix, tp.ns,
+                                      w.sub, w.sub_bytes, stream))) return rc;
         if ((rc = gs_project_active(map_points, map_counts, B, Nmax, prev_poses, intrinsics, H, W, ds, w.rows, w.nrows, w.sub,
                                     w.sub_bytes, stream))) return rc;
         if ((rc = gs_build_icp_target(w.rows, w.nrows, (int64_t)B * Nmax, B, H, W, ds, map_points, map_normals, Nmax, capT, w.tgt,
