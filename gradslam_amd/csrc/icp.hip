@@ -1235,16 +1235,8 @@ __global__ __launch_bounds__(1024) void icp_step_k(IcpState *__restrict__ Sg, co
 #ifdef GS_DIAG_STAMPS
     if (g_diag && threadIdx.x == 0) g_diag[0] = wall_clock64();
 #endif
-    if (nblocks <= 32 * RP_LOADS) {  // one round of rows: requested together with the state, before either is waited for
-        float a[RP_LOADS];
-        rp_issue(partials, nblocks, (int)(threadIdx.x >> 5), a);
-        const int sw = reinterpret_cast<const int *>(Sg)[min((int)threadIdx.x, kWords - 1)];
-        if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = sw;
-        rp_finish(rp_sum(a, nblocks, (int)(threadIdx.x >> 5), 0.0f), acc);  // ends with a barrier: st and acc are visible
-    } else {
-        if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
-        reduce_partials(partials, nblocks, acc);  // ends with a barrier: st and acc are visible
-    }
+    if (threadIdx.x < kWords) reinterpret_cast<int *>(&st)[threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
+    reduce_partials(partials, nblocks, acc);  // ends with a barrier: st and acc are visible
     // (from the global copy: wave 0 is about to change the LDS one)
     if (rec && threadIdx.x < kWords) reinterpret_cast<int *>(rec)[REC_STATE + threadIdx.x] = reinterpret_cast<const int *>(Sg)[threadIdx.x];
 #ifdef GS_DIAG_STAMPS

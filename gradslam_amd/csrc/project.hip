@@ -211,15 +211,7 @@ __global__ __launch_bounds__(1024) void pix_scan_k(const int *__restrict__ cnt, 
     __syncthreads();
     for (int t0 = 0; t0 < npix; t0 += PIX_TILE) {
         const int nb = min(PIX_TILE, npix - t0);
-        {   // all of the thread's loads before any of their LDS stores (a load -> store loop of unknown length ran them as
-            // up to 24 round trips in a row)
-            int r[PIX_TILE / 1024];
-#pragma unroll
-            for (int u = 0; u < PIX_TILE / 1024; ++u) r[u] = cnt[t0 + min((int)threadIdx.x + 1024 * u, nb - 1)];
-#pragma unroll
-            for (int u = 0; u < PIX_TILE / 1024; ++u)
-                if ((int)threadIdx.x + 1024 * u < nb) bins[threadIdx.x + 1024 * u] = r[u];
-        }
+        for (int i = threadIdx.x; i < nb; i += 1024) bins[i] = cnt[t0 + i];
         __syncthreads();
         const int per = (nb + 1023) / 1024;
         const int i0 = min(nb, (int)threadIdx.x * per), i1 = min(nb, i0 + per);
