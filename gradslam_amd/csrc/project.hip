@@ -383,7 +383,12 @@ int project_target1(const float *points, const int32_t *counts, int Nmax, const 
         DsPred dp{frame->depth, W, Wd, ds};
         DsWriter dw{frame->gvertex, nullptr, nullptr, frame->out_points, nullptr, nullptr, frame->out_pix, W, Wd, ds};
         void *dws = (char *)flags + compact_flags_bytes(Nmax);  // (the frame's block counts: behind everything the projection uses)
-        rc = compact_launch2((int64_t)Nmax, pred, wr, nrows, cws, flags, (int64_t)Hd * Wd, dp, dw, frame->count, dws, st, name);
+        if (compact_blocks((int64_t)Hd * Wd) <= kSelfScanBlocks) {
+            rc = compact_launch2((int64_t)Nmax, pred, wr, nrows, cws, flags, (int64_t)Hd * Wd, dp, dw, frame->count, dws, st, name);
+        } else {  // a ds-grid of more than a million pixels: its write pass needs the scan launch, so it goes by itself
+            rc = compact_launch((int64_t)Hd * Wd, dp, dw, frame->count, dws, st, name);
+            if (rc == GS_OK) rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name, flags);
+        }
     } else {
         rc = compact_launch((int64_t)Nmax, pred, wr, nrows, cws, st, name, flags);
     }

@@ -1622,3 +1622,24 @@ def test_sequence_node_batch_equals_single_runs(gs, odom):
             for name, g, sg in zip(("colors", "depths", "intrinsics", "poses"), grads, sgrads):
                 e = rel_err(g[b].cpu(), sg[0].cpu())
                 assert e < 1e-5, (odom, grow, b, name, e)
+
+@pytest.mark.gpu
+def test_localize_with_a_ds_grid_of_more_than_a_million_pixels(gs):
+    """gs_slam_localize stages the frame's ds-grid source cloud on the launches of the map's projection (two compactions per
+    launch); a ds-grid that needs more than 1024 compaction blocks (> 2^20 pixels: its write pass needs the scan launch)
+    must take the separate form instead of failing.  numiters = 0: the target is built, the pose is the previous one."""
+    dev = torch.device("cuda:0")
+    H, W = 1056, 1024  # 1 081 344 pixels at ds = 1 -> 1056 compaction blocks
+    g = torch.Generator().manual_seed(7)
+    depth = (1.0 + torch.rand((1, 1, H, W, 1), generator=g)).to(dev)
+    depth[0, 0, ::7, ::5] = 0.0  # holes
+    K = torch.eye(4).reshape(1, 1, 4, 4).clone()
+    K[0, 0, 0, 0] = K[0, 0, 1, 1] = 500.0; K[0, 0, 0, 2] = W / 2; K[0, 0, 1, 2] = H / 2
+    prev = torch.eye(4).reshape(1, 1, 4, 4).clone()
+    prev[0, 0, 0, 3] = 0.1
+    mp = torch.rand((1, 4096, 3), generator=g).to(dev) + torch.tensor([0.0, 0.0, 1.0], device=dev)
+    mn = torch.nn.functional.normalize(torch.rand((1, 4096, 3), generator=g), dim=-1).to(dev)
+    cnt = torch.tensor([4096], dtype=torch.int32, device=dev)
+    poses, _, _ = gs.ops.slam_localize_raw(depth, K.to(dev), prev.to(dev), mp, mn, cnt, 1, 0, 1e-8, None, want_maps=False)
+    torch.cuda.synchronize()
+    assert torch.equal(poses.cpu(), prev)
