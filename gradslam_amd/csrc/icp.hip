@@ -1214,10 +1214,12 @@ __device__ __forceinline__ void step_wave0(IcpState *S, const float *acc, int mo
         if (mode != STEP_ADOPT) S->it += 1;
     }
     wave_sync();
+    GS_STAMP(13);  // (diagnostic build, wave 0: decision taken, state updated)
     if (out_T && t < 16) out_T[t] = S->T[t];
     if (solve && mode != STEP_GRAD_B) {  // wave-uniform
         solve6_wave(S->cur, S->cur + 36, S->damp, S->xi, lu_buf);
         wave_sync();
+        GS_STAMP(14);  // (solved)
         if (t == 0) se3_exp_dev(S->xi, S->dT);
     }
     wave_sync();

@@ -112,6 +112,7 @@ if (a[..., 9] > 0).any():
     for k in sorted(set(share)):
         m = share == k
         r = lambda arr: np.percentile(((arr - a[..., 6]) * tick)[m], 50)
-        print("  %d block(s) on the CU: first batch arrived %.2f | rows summed %.2f | wave 0: step done %.2f (us after kernel entry, p50)" % (
-            k, r(a[..., 8]), r(a[..., 9]), np.percentile(((w0[..., 10] - w0[..., 6]) * tick)[m], 50)))
+        w0r = lambda slot: np.percentile(((w0[..., slot] - w0[..., 6]) * tick)[m], 50)
+        print("  %d block(s) on the CU: first batch arrived %.2f | rows summed %.2f | wave 0: sums ready %.2f, decision + state %.2f, solved %.2f, step done %.2f (us after kernel entry, p50)" % (
+            k, r(a[..., 8]), r(a[..., 9]), w0r(9), w0r(13), w0r(14), w0r(10)))
 print("blocks per XCC:", dict(zip(*np.unique(xcc, return_counts=True))))
