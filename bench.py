@@ -567,8 +567,8 @@ def main():
                 "timing_source": "HIP events on the launch stream, second eager pass of {} steps".format(n_prof),
                 "hbm_view": {"algorithmic_bytes_per_launch": 40.0 * ns, "achieved_GBps": round(40.0 * ns / (avg_knn_ms * 1e-3) / 1e9, 2)
                              if n_knn else 0.0, "frac_of_8TBps": round(40.0 * ns / (avg_knn_ms * 1e-3) / 8e12, 5) if n_knn else 0.0,
-                             "note": "0.77 MB per launch lives in L2: not an HBM measurement (fetched bytes per launch: "
-                                     "profiles/r01t_pmc_knn1_loop.json)"},
+                             "note": "0.77 MB per launch lives in L2: not an HBM measurement (fetched / written bytes per launch from "
+                                     "counter passes: profiles/r05_pmc_knn1_loop_traffic.json -- 1.8 MiB / 0.45 MiB raw)"},
                 "valu_view": valu if valu is not None else {"note": "no committed counter pass found under profiles/"}},
         }
         try:
