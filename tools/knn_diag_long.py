@@ -115,4 +115,9 @@ if (a[..., 9] > 0).any():
         w0r = lambda slot: np.percentile(((w0[..., slot] - w0[..., 6]) * tick)[m], 50)
         print("  %d block(s) on the CU: first batch arrived %.2f | rows summed %.2f | wave 0: sums ready %.2f, decision + state %.2f, solved %.2f, step done %.2f (us after kernel entry, p50)" % (
             k, r(a[..., 8]), r(a[..., 9]), w0r(9), w0r(13), w0r(14), w0r(10)))
+if (a[..., 15] > 0).any() and a.shape[1] > 3:
+    solo = share == min(set(share))
+    wrel = lambda w, slot: np.percentile(((a[:, w, slot] - a[:, w, 6]) * tick)[solo & (a[:, w, slot] > 0)], 50)
+    print("  per role (blocks alone on their CU, p50 us after kernel entry): wave 1 (planner) centre %.2f plan published %.2f staged %.2f | wave 2 (lanes) plan seen %.2f rows packed + staged %.2f | wave 3 (stager) plan seen %.2f staged %.2f | barrier passed %.2f" % (
+        wrel(1, 13), wrel(1, 14), wrel(1, 15), wrel(2, 14), wrel(2, 15), wrel(3, 14), wrel(3, 15), wrel(3, 7)))
 print("blocks per XCC:", dict(zip(*np.unique(xcc, return_counts=True))))
