@@ -2714,7 +2714,7 @@ int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_po
     const int tp = loop_tile_points();
     if (blocks) *blocks = cdiv(max_ns, tp);
     if (tile_points_dense) *tile_points_dense = tp;
-    if (partial_rows) *partial_rows = loop_blocks_max(max_ns);
+    if (partial_rows) *partial_rows = partial_rows_alloc(max_ns);
     return GS_OK;
 }
 

@@ -44,7 +44,7 @@ def test_icp_launch_geometry_fits_the_workspace():
         assert lib.gs_icp_launch_geometry(max_ns, hints, ctypes.byref(b), ctypes.byref(t), ctypes.byref(r)) == 0
         return b.value, t.value, r.value
 
-    assert geom(19200, 1) == (300, 64, 600)          # 160 x 120 ds-grid
+    assert geom(19200, 1) == (300, 64, 601)          # 160 x 120 ds-grid (rows: 32-point tiles' worth + the spare row)
     assert geom(19200, 0)[:2] == (300, 64)
     assert geom(16385, 1)[:2] == (257, 64)
     assert geom(78408, 1)[:2] == (1226, 64)           # more blocks than the chip holds: unfolded steps
@@ -54,7 +54,7 @@ def test_icp_launch_geometry_fits_the_workspace():
             for max_ns in (1, 63, 64, 65, 4800, 16385, 19200, 32768, 100000):
                 for hints in (0, 1):
                     blocks, tile, rows = geom(max_ns, hints)
-                    assert 32 <= tile <= 64 and blocks * tile >= max_ns and blocks <= rows, (forced, max_ns, hints)
+                    assert 32 <= tile <= 64 and blocks * tile >= max_ns and blocks < rows and rows >= 513, (forced, max_ns, hints)
                     if forced:
                         assert tile == forced
     finally:
