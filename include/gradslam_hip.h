@@ -408,9 +408,9 @@ void gs_set_grid_search(int on);
 void gs_set_tile_points(int n);
 /* Launch geometry of one association launch of the loops above for a source capacity (host-side query, no device
  * work): blocks launched, source points per block, and the number of partial rows the workspace (gs_icp_ws_bytes)
- * holds per buffer (>= blocks for every tile-size setting, and >= 513: the association kernel's prologue sums 512 rows
- * unmasked -- rows no block writes are kept at zero -- and reads up to twelve bytes past a row).  have_hints is ignored
- * since ABI 3. */
+ * holds per buffer (>= blocks for every tile-size setting).  The rows are padded to at least 513: the association
+ * kernel's prologue sums 512 rows unmasked (rows no block writes are kept at zero) and reads up to twelve bytes past a
+ * row.  have_hints is ignored since ABI 3. */
 int gs_icp_launch_geometry(int max_ns, int have_hints, int *blocks, int *tile_points_dense, int *partial_rows);
 /* Counters kept on the DEVICE for the loops run so far: out4 = {loops, loops associated by grid search, loops with a
  * forced tile size (gs_set_tile_points), tiles whose point-serial straggler search overflowed its pair list and was
