@@ -1,6 +1,15 @@
 #!/usr/bin/env python3
 """Diagnostic only: phase stamps of the LAST association launch of a long streamed PointFusion run, i.e. with
-the ICP target grown to the downsampled active map (needs make -C gradslam_amd/csrc diag)."""
+the ICP target grown to the downsampled active map (needs make -C gradslam_amd/csrc diag).
+
+Stamp slots per wave (16 x 8 bytes per wave, GS_STAMP / GS_COUNT in icp.hip; times are s_memrealtime ticks of 10 ns):
+  6 kernel entry | 8 first batch of requests arrived | 9 row sums handed over (wave 0: sums ready) | 7 prologue barrier passed
+  wave 0 (the folded step): 13 decision taken + state updated | 14 6x6 system solved | 10 step done
+  wave 1 (planner): 13 window centres + majority displacement known | 14 plan published | 15 its share staged
+  waves 2.. : 14 plan seen | 15 staged (wave 2, the lanes' wave: rows packed)
+  0 / 1 / 2 / 3 search start / window scan done / proof + fallbacks done / end ; 5 (wave 0) HW_ID | XCC_ID: which CU
+Every stamp costs ~0.1 us: compare runs of the same build, not absolute values with the product's timings.
+Printed: the phases' percentiles, the same split by how many blocks share a CU, per role, and the old chunk-box figures."""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
